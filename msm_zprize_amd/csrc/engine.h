@@ -1,0 +1,560 @@
+// Host-side MSM engine: owns the device buffers of one GPU, sequences the kernels on one HIP stream
+// and finishes the K window sums on the host.  This replaces the reference's SPMD worker runtime
+// (src/threads/threads.ts:132-359, src/parallel.ts:291-320) and the JS orchestration inside
+// `msm` (src/msm-batched-affine.ts:74-328): barriers between phases become stream order, the
+// per-thread bucket split (msm-common.ts:88-188) becomes grid sizing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "../../include/msmz.h"
+#include "kernels.h"
+#include "gen_kernels.h"
+
+namespace msmz {
+
+#define MSMZ_HIP(x)                                                                        \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      fprintf(stderr, "msmz: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MSMZ_ERR_HIP;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {   // grow-only
+    if (need <= bytes) return MSMZ_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t sz = need + need / 8;
+    if (hipMalloc(&p, sz) != hipSuccess) {
+      if (hipMalloc(&p, need) != hipSuccess) return MSMZ_ERR_HIP;
+      sz = need;
+    }
+    bytes = sz;
+    return MSMZ_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct Handle {
+  int kind;        // 0 = points, 1 = scalars
+  uint64_t n;
+  bool has_endo;   // points: records [n, 2n) hold the endomorphism images
+  void* dev;
+};
+
+class IEngine {
+ public:
+  virtual ~IEngine() {}
+  virtual int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h) = 0;
+  virtual int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h) = 0;
+  virtual int random_points(uint64_t n, uint64_t seed, uint64_t* h) = 0;
+  virtual int random_scalars(uint64_t n, uint64_t seed, uint64_t* h) = 0;
+  virtual int download_points(uint64_t h, uint64_t first, uint64_t count, uint8_t* xy, uint8_t* inf) = 0;
+  virtual int download_scalars(uint64_t h, uint64_t first, uint64_t count, uint8_t* s) = 0;
+  virtual int free_handle(uint64_t h) = 0;
+  virtual int msm(uint64_t ph, const uint8_t* host_scalars, uint64_t sh, uint64_t n, const msmz_opts* o, uint8_t* out,
+                  int* out_inf, msmz_log* log) = 0;
+};
+
+static inline int ceil_log2_u64(uint64_t x) {
+  int r = 0;
+  while (((uint64_t)1 << r) < x) r++;
+  return r;
+}
+
+// default window size.  The reference's tables (msm-common.ts:8-57) were tuned for 16 CPU threads;
+// on the GPU the accumulate phase costs ~N*K additions and the reduction ~2*K*2^(c-1), and the latter
+// is latency-bound, so c stays well below log2(N).
+static inline int default_window(uint64_t n_points) {
+  int lg = ceil_log2_u64(n_points < 2 ? 2 : n_points);
+  int c = lg - 4;
+  if (c < 3) c = 3;
+  if (c > 16) c = 16;
+  return c;
+}
+
+template <class Cfg>
+class Engine : public IEngine {
+  using F = typename Cfg::F;
+  using Fr = typename Cfg::Fr;
+  static constexpr int NW = F::NW;
+  static constexpr int RW = 2 * NW;      // affine record words
+  static constexpr int XW = 4 * NW;      // XYZZ / extended record words
+  static constexpr int FE_BYTES = NW * 4;
+
+ public:
+  explicit Engine(int device) : device_(device) {}
+
+  int init() {
+    MSMZ_HIP(hipSetDevice(device_));
+    MSMZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    for (auto& e : ev_) MSMZ_HIP(hipEventCreate(&e));
+    MSMZ_HIP(hipHostMalloc(&h_meta_, sizeof(MsmMeta)));
+    MSMZ_HIP(hipHostMalloc(&h_final_, (size_t)2 * 64 * XW * 4));
+    return meta_.ensure(sizeof(MsmMeta));
+  }
+
+  ~Engine() override {
+    (void)hipSetDevice(device_);
+    for (auto& kv : handles_) (void)hipFree(kv.second.dev);
+    for (DevBuf* b : {&digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+                      &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
+      b->release();
+    if (h_meta_) (void)hipHostFree(h_meta_);
+    if (h_final_) (void)hipHostFree(h_final_);
+    for (auto& e : ev_)
+      if (e) (void)hipEventDestroy(e);
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+
+  // ------------------------------------------------------------------------------------------ data
+  int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h) override {
+    if (!xy || !h || n == 0 || n >= (1ull << 30)) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    // range check on the host: coordinates must be canonical (< p)
+    for (uint64_t i = 0; i < 2 * n; i++) {
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(xy + i * FE_BYTES);
+      uint32_t tmp[NW];
+      memcpy(tmp, w, FE_BYTES);
+      if (words_geq<NW>(tmp, F::PW)) return MSMZ_ERR_RANGE;
+    }
+    int st = stage_.ensure(n * RW * 4 + n);
+    if (st) return st;
+    MSMZ_HIP(hipMemcpyAsync(stage_.p, xy, n * RW * 4, hipMemcpyHostToDevice, stream_));
+    uint8_t* d_inf = nullptr;
+    if (inf) {
+      d_inf = stage_.as<uint8_t>() + n * RW * 4;
+      MSMZ_HIP(hipMemcpyAsync(d_inf, inf, n, hipMemcpyHostToDevice, stream_));
+    }
+    const bool endo = Cfg::HAS_ENDO;
+    void* dev = nullptr;
+    MSMZ_HIP(hipMalloc(&dev, (size_t)n * RW * 4 * (endo ? 2 : 1)));
+    hipLaunchKernelGGL((k_points_to_mont<F>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)dev,
+                       stage_.as<uint32_t>(), d_inf, (uint32_t)n, endo ? 1 : 0);
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    *h = next_handle_++;
+    handles_[*h] = Handle{0, n, endo, dev};
+    return MSMZ_OK;
+  }
+
+  int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h) override {
+    if (!s || !h || n == 0) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    int st = check_scalars(s, n);
+    if (st) return st;
+    void* dev = nullptr;
+    MSMZ_HIP(hipMalloc(&dev, n * 32));
+    MSMZ_HIP(hipMemcpyAsync(dev, s, n * 32, hipMemcpyHostToDevice, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    *h = next_handle_++;
+    handles_[*h] = Handle{1, n, false, dev};
+    return MSMZ_OK;
+  }
+
+  int random_points(uint64_t n, uint64_t seed, uint64_t* h) override {
+    if (!h || n == 0 || n >= (1ull << 30)) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    int st = ensure_gen_table();
+    if (st) return st;
+    const bool endo = Cfg::HAS_ENDO;
+    void* dev = nullptr;
+    MSMZ_HIP(hipMalloc(&dev, (size_t)n * RW * 4 * (endo ? 2 : 1)));
+    hipLaunchKernelGGL((k_gen_points<F>), dim3((n + 127) / 128), dim3(128), 0, stream_, (uint32_t*)dev,
+                       gen_table_.as<uint32_t>(), (uint32_t)n, seed, endo ? 1 : 0);
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    *h = next_handle_++;
+    handles_[*h] = Handle{0, n, endo, dev};
+    return MSMZ_OK;
+  }
+
+  int random_scalars(uint64_t n, uint64_t seed, uint64_t* h) override {
+    if (!h || n == 0) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    void* dev = nullptr;
+    MSMZ_HIP(hipMalloc(&dev, n * 32));
+    hipLaunchKernelGGL((k_gen_scalars<Fr>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)dev, (uint32_t)n,
+                       seed);
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    *h = next_handle_++;
+    handles_[*h] = Handle{1, n, false, dev};
+    return MSMZ_OK;
+  }
+
+  int download_points(uint64_t hd, uint64_t first, uint64_t count, uint8_t* xy, uint8_t* inf) override {
+    auto it = handles_.find(hd);
+    if (it == handles_.end() || it->second.kind != 0 || !xy) return MSMZ_ERR_ARG;
+    if (first + count > it->second.n * (it->second.has_endo ? 2 : 1)) return MSMZ_ERR_ARG;
+    if (count == 0) return MSMZ_OK;
+    MSMZ_HIP(hipSetDevice(device_));
+    int st = stage_.ensure(count * RW * 4);
+    if (st) return st;
+    hipLaunchKernelGGL((k_points_from_mont<F>), dim3((count + 255) / 256), dim3(256), 0, stream_,
+                       stage_.as<uint32_t>(), (const uint32_t*)it->second.dev + first * RW, (uint32_t)count);
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipMemcpyAsync(xy, stage_.p, count * RW * 4, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    if (inf) {
+      for (uint64_t i = 0; i < count; i++) {
+        bool z = true;
+        for (int j = 0; j < RW * 4; j++) z = z && xy[i * RW * 4 + j] == 0;
+        inf[i] = z ? 1 : 0;
+      }
+    }
+    return MSMZ_OK;
+  }
+
+  int download_scalars(uint64_t hd, uint64_t first, uint64_t count, uint8_t* s) override {
+    auto it = handles_.find(hd);
+    if (it == handles_.end() || it->second.kind != 1 || !s || first + count > it->second.n) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    MSMZ_HIP(hipMemcpy(s, (const uint8_t*)it->second.dev + first * 32, count * 32, hipMemcpyDeviceToHost));
+    return MSMZ_OK;
+  }
+
+  int free_handle(uint64_t hd) override {
+    auto it = handles_.find(hd);
+    if (it == handles_.end()) return MSMZ_ERR_ARG;
+    (void)hipSetDevice(device_);
+    (void)hipFree(it->second.dev);
+    handles_.erase(it);
+    return MSMZ_OK;
+  }
+
+  // ------------------------------------------------------------------------------------------ msm
+  int msm(uint64_t ph, const uint8_t* host_scalars, uint64_t sh, uint64_t n, const msmz_opts* o, uint8_t* out,
+          int* out_inf, msmz_log* log) override {
+    auto t_begin = std::chrono::steady_clock::now();
+    if (!out || !out_inf || n == 0) return MSMZ_ERR_ARG;
+    auto pit = handles_.find(ph);
+    if (pit == handles_.end() || pit->second.kind != 0 || pit->second.n < n) return MSMZ_ERR_ARG;
+    msmz_opts opt;
+    memset(&opt, 0, sizeof(opt));
+    if (o) opt = *o;
+    MSMZ_HIP(hipSetDevice(device_));
+
+    const uint32_t* d_scalars = nullptr;
+    if (host_scalars) {
+      int st = check_scalars(host_scalars, n);
+      if (st) return st;
+      st = stage_.ensure(n * 32);
+      if (st) return st;
+      MSMZ_HIP(hipMemcpyAsync(stage_.p, host_scalars, n * 32, hipMemcpyHostToDevice, stream_));
+      d_scalars = stage_.as<uint32_t>();
+    } else {
+      auto sit = handles_.find(sh);
+      if (sit == handles_.end() || sit->second.kind != 1 || sit->second.n < n) return MSMZ_ERR_ARG;
+      d_scalars = (const uint32_t*)sit->second.dev;
+    }
+    if (log) memset(log, 0, sizeof(*log));
+    int st = Cfg::run_msm(*this, pit->second, d_scalars, n, opt, out, out_inf, log);
+    if (log) {
+      log->stage_ms[MSMZ_ST_TOTAL] =
+          std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return st;
+  }
+
+  // ------------------------------------------------------------------------------------------ Weierstrass, affine buckets
+  int msm_weierstrass_affine(const Handle& pts, const uint32_t* d_scalars, uint64_t n64, const msmz_opts& opt,
+                             uint8_t* out, int* out_inf, msmz_log* log) {
+    const uint32_t n = (uint32_t)n64;
+    const bool glv = opt.glv != 0;
+    if (glv && (!Fr::HAS_GLV || !pts.has_endo)) return MSMZ_ERR_UNSUPPORTED;
+    // GLV addresses the endomorphism images at index handle.n + i, so the MSM must cover the whole set
+    if (glv && n != pts.n) return MSMZ_ERR_UNSUPPORTED;
+    const uint32_t M = glv ? 2 * n : n;
+    const int b = glv ? Fr::GLV_BITS - 1 : Fr::BITS;      // scalar bit length
+    int c = opt.c > 0 ? opt.c : default_window(M);
+    if (c < 2) c = 2;
+    if (c > 24) c = 24;
+    const int K = (b + 1 + c - 1) / c;                    // msm-batched-affine.ts:96
+    const uint32_t L = 1u << (c - 1);
+    const uint64_t nb64 = (uint64_t)K * L;
+    if (nb64 + 1 >= (1ull << 31) || (uint64_t)K * M >= (1ull << 31) || K > 64) return MSMZ_ERR_ARG;
+    const uint32_t nb = (uint32_t)nb64;
+    const bool timing = opt.timing != 0;
+    int ei = 0;
+    auto mark = [&]() {
+      if (timing && ei < kMaxEvents) (void)hipEventRecord(ev_[ei++], stream_);
+    };
+
+    int st;
+    if ((st = digits_.ensure((size_t)K * M * 4))) return st;
+    if ((st = refs_.ensure((size_t)K * M * 4))) return st;
+    if ((st = counts_.ensure(((size_t)nb + 1) * 4))) return st;
+    if ((st = off_.ensure(((size_t)nb + 1) * 4))) return st;
+    if ((st = cursor_.ensure((size_t)nb * 4))) return st;
+    const uint32_t nblocks = (nb + SCAN_TILE - 1) / SCAN_TILE;
+    if ((st = partials_.ensure((size_t)32 * nblocks * 4))) return st;
+    if ((st = slots_.ensure((size_t)K * M * RW * 4))) return st;
+
+    MsmMeta* d_meta = meta_.as<MsmMeta>();
+    MSMZ_HIP(hipMemsetAsync(d_meta, 0, sizeof(MsmMeta), stream_));
+    MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nb + 1) * 4, stream_));
+    MSMZ_HIP(hipMemsetAsync(cursor_.p, 0, (size_t)nb * 4, stream_));
+
+    mark();  // 0
+    if (glv) {
+      hipLaunchKernelGGL((k_digits<Fr, true>), dim3((n + 255) / 256), dim3(256), 0, stream_, digits_.as<uint32_t>(),
+                         counts_.as<uint32_t>(), d_scalars, n, c, K);
+    } else {
+      hipLaunchKernelGGL((k_digits<Fr, false>), dim3((n + 255) / 256), dim3(256), 0, stream_, digits_.as<uint32_t>(),
+                         counts_.as<uint32_t>(), d_scalars, n, c, K);
+    }
+    mark();  // 1
+    // bucket offsets + max bucket size + total entries
+    hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
+                       counts_.as<uint32_t>(), nb, 0, nblocks);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
+                       &d_meta->n_entries);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, off_.as<uint32_t>(),
+                       partials_.as<uint32_t>(), counts_.as<uint32_t>(), nb, 0, nblocks, (size_t)0,
+                       &d_meta->max_bucket);
+    mark();  // 2
+    {
+      dim3 grid((M + 256 * 4 - 1) / (256 * 4), K);
+      hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, stream_, refs_.as<uint32_t>(), cursor_.as<uint32_t>(),
+                         off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c);
+    }
+    mark();  // 3
+    MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    const uint32_t max_bucket = h_meta_->max_bucket;
+    const uint32_t n_entries = h_meta_->n_entries;
+    const int R = max_bucket <= 1 ? 0 : ceil_log2_u64(max_bucket);   // rounds m = 1, 2, 4, ... < max_bucket
+    if (R > 31) return MSMZ_ERR_ARG;
+
+    mark();  // 4
+    if (R > 0) {
+      if ((st = rscan_.ensure((size_t)R * ((size_t)nb + 1) * 4))) return st;
+      hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, R), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
+                         off_.as<uint32_t>(), nb, 1, nblocks);
+      hipLaunchKernelGGL(k_scan_top, dim3(R), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
+                         d_meta->round_pairs);
+      hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, R), dim3(SCAN_T), 0, stream_, rscan_.as<uint32_t>(),
+                         partials_.as<uint32_t>(), off_.as<uint32_t>(), nb, 1, nblocks, (size_t)nb + 1,
+                         (uint32_t*)nullptr);
+      MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
+      MSMZ_HIP(hipStreamSynchronize(stream_));
+    }
+    mark();  // 5
+    uint64_t n_pairs = 0;
+    const uint32_t* d_points = (const uint32_t*)pts.dev;
+    int round_ev0 = ei;
+    for (int r = 0; r < R; r++) {
+      const uint32_t pairs = h_meta_->round_pairs[r];
+      n_pairs += pairs;
+      if (pairs == 0) continue;
+      const uint32_t* rs = rscan_.as<uint32_t>() + (size_t)r * ((size_t)nb + 1);
+      launch_batch_add(pairs, opt.safe != 0, d_points, rs, nb, r, d_meta);
+      mark();
+    }
+    int round_ev1 = ei;
+    mark();  // accumulate end
+
+    // ---- bucket reduction: level 1 from affine bucket sums, then XYZZ levels down to one entry per window
+    uint32_t S1 = 2;
+    while ((uint64_t)K * (L / (S1 * 2)) >= 131072 && S1 * 2 <= L && S1 < 16) S1 *= 2;
+    if (S1 > L) S1 = L;
+    uint32_t groups = (L + S1 - 1) / S1;
+    if ((st = red_[0].ensure((size_t)K * groups * XW * 4))) return st;
+    if ((st = red_[1].ensure((size_t)K * groups * XW * 4))) return st;
+    {
+      uint32_t total = K * groups;
+      hipLaunchKernelGGL((k_reduce_first<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
+                         red_[0].as<uint32_t>(), red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points,
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), L, S1, groups, total);
+    }
+    int shift = ceil_log2_u64(S1);
+    int cur = 0;   // rows in red_[cur*2], C in red_[cur*2+1]
+    uint32_t n_in = groups;
+    while (n_in > 1) {
+      uint32_t S = n_in <= 8 ? (1u << ceil_log2_u64(n_in)) : 4;
+      uint32_t g2 = (n_in + S - 1) / S;
+      int nxt = cur ^ 1;
+      if ((st = red_[nxt * 2].ensure((size_t)K * g2 * XW * 4))) return st;
+      if ((st = red_[nxt * 2 + 1].ensure((size_t)K * g2 * XW * 4))) return st;
+      uint32_t total = K * g2;
+      hipLaunchKernelGGL((k_reduce_next<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
+                         red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(), red_[cur * 2].as<uint32_t>(),
+                         red_[cur * 2 + 1].as<uint32_t>(), n_in, S, g2, total, shift);
+      shift += ceil_log2_u64(S);
+      n_in = g2;
+      cur = nxt;
+    }
+    mark();  // reduce end
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipMemcpyAsync(h_final_, red_[cur * 2].p, (size_t)K * XW * 4, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)64 * XW, red_[cur * 2 + 1].p, (size_t)K * XW * 4,
+                            hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    auto t_host0 = std::chrono::steady_clock::now();
+    if (h_meta_->error & 1u) return MSMZ_ERR_DEGENERATE;
+
+    // ---- final sum on the host (msm-batched-affine.ts:300-322): W_k = C_k + row_k, Horner over windows
+    Xyzz<F> acc;
+    xyzz_set_inf(acc);
+    for (int k = K - 1; k >= 0; k--) {
+      if (k != K - 1)
+        for (int j = 0; j < c; j++) {
+          Xyzz<F> t;
+          xyzz_dbl(t, acc);
+          acc = t;
+        }
+      Xyzz<F> row, cc, w, t;
+      host_load_xyzz(row, h_final_ + (size_t)k * XW);
+      host_load_xyzz(cc, h_final_ + (size_t)(64 + k) * XW);
+      xyzz_add(w, row, cc);
+      xyzz_add(t, acc, w);
+      acc = t;
+    }
+    uint32_t res[RW];
+    bool inf = xyzz_to_affine_canon<F>(res, acc);
+    memcpy(out, res, RW * 4);
+    *out_inf = inf ? 1 : 0;
+
+    if (log) {
+      log->c = c;
+      log->K = K;
+      log->rounds = R;
+      log->glv = glv ? 1 : 0;
+      log->n_entries = n_entries;
+      log->n_pairs = n_pairs;
+      log->max_bucket = max_bucket;
+      log->stage_ms[MSMZ_ST_FINAL] =
+          std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+      if (timing) {
+        auto el = [&](int a, int b2) {
+          float ms = 0;
+          (void)hipEventElapsedTime(&ms, ev_[a], ev_[b2]);
+          return ms;
+        };
+        log->stage_ms[MSMZ_ST_DIGITS] = el(0, 1);
+        log->stage_ms[MSMZ_ST_SCAN] = el(1, 2);
+        log->stage_ms[MSMZ_ST_SCATTER] = el(2, 3);
+        log->scatter_kernel_ms = el(2, 3);
+        log->scatter_launches = 1;
+        log->stage_ms[MSMZ_ST_PLAN] = el(4, 5);
+        log->stage_ms[MSMZ_ST_ACCUMULATE] = el(5, round_ev1);
+        log->stage_ms[MSMZ_ST_REDUCE] = el(round_ev1, round_ev1 + 1);
+        int prev = 5, rr = 0;
+        for (int r = 0; r < R && rr < 32; r++) {
+          if (h_meta_->round_pairs[r] == 0) continue;
+          int e = round_ev0 + rr;
+          if (e >= kMaxEvents) break;
+          log->batch_add_ms[r] = el(prev, e);
+          prev = e;
+          rr++;
+        }
+      }
+    }
+    return MSMZ_OK;
+  }
+
+  void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb, int r,
+                        MsmMeta* d_meta) {
+    constexpr int T = Cfg::BATCH_T;
+    dim3 grid((pairs + T - 1) / T), block(T);
+    if (safe) {
+      hipLaunchKernelGGL((k_batch_add<F, T, true>), grid, block, 0, stream_, slots_.as<uint32_t>(), d_points,
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, d_meta);
+    } else {
+      hipLaunchKernelGGL((k_batch_add<F, T, false>), grid, block, 0, stream_, slots_.as<uint32_t>(), d_points,
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, d_meta);
+    }
+  }
+
+  static void host_load_xyzz(Xyzz<F>& p, const uint32_t* w) {
+    fe_unpack<F>(p.X, w);
+    fe_unpack<F>(p.Y, w + NW);
+    fe_unpack<F>(p.ZZ, w + 2 * NW);
+    fe_unpack<F>(p.ZZZ, w + 3 * NW);
+  }
+
+  int check_scalars(const uint8_t* s, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) {
+      uint32_t w[8];
+      memcpy(w, s + i * 32, 32);
+      if (words_geq<8>(w, Fr::Q)) return MSMZ_ERR_RANGE;
+    }
+    return MSMZ_OK;
+  }
+
+  int ensure_gen_table() {
+    if (gen_table_.p) return MSMZ_OK;
+    int st = gen_table_.ensure((size_t)GEN_WINDOWS * GEN_TABLE * RW * 4);
+    if (st) return st;
+    // bases 2^(13 k) * G computed on the host, multiples on the device
+    uint32_t bases[GEN_WINDOWS * RW];
+    Xyzz<F> g;
+    Affine<F> ga;
+    fe_set_const<F>(ga.x, F::GX);
+    fe_set_const<F>(ga.y, F::GY);
+    xyzz_from_affine(g, ga);
+    for (int k = 0; k < GEN_WINDOWS; k++) {
+      // store affine (Montgomery, lazy) of the current base
+      Affine<F> a;
+      host_xyzz_to_affine_mont(a, g);
+      fe_store<F>(bases + k * RW, a.x);
+      fe_store<F>(bases + k * RW + NW, a.y);
+      for (int j = 0; j < GEN_BITS; j++) {
+        Xyzz<F> t;
+        xyzz_dbl(t, g);
+        g = t;
+      }
+    }
+    st = stage_.ensure(sizeof(bases));
+    if (st) return st;
+    MSMZ_HIP(hipMemcpyAsync(stage_.p, bases, sizeof(bases), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL((k_gen_table<F>), dim3((GEN_WINDOWS * GEN_TABLE + 127) / 128), dim3(128), 0, stream_,
+                       gen_table_.as<uint32_t>(), stage_.as<uint32_t>());
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    return MSMZ_OK;
+  }
+
+  static void host_xyzz_to_affine_mont(Affine<F>& a, const Xyzz<F>& p) {
+    Fe<F> zi3, t, zi2;
+    fe_inverse(zi3, p.ZZZ);
+    fe_mul(t, zi3, p.ZZ);
+    fe_sqr(zi2, t);
+    fe_mul(a.x, p.X, zi2);
+    fe_mul(a.y, p.Y, zi3);
+  }
+
+  // shared state -------------------------------------------------------------------------------
+  static constexpr int kMaxEvents = 64;
+  int device_;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev_[kMaxEvents] = {};
+  std::map<uint64_t, Handle> handles_;
+  uint64_t next_handle_ = 1;
+  DevBuf digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  MsmMeta* h_meta_ = nullptr;
+  uint32_t* h_final_ = nullptr;
+};
+
+}  // namespace msmz

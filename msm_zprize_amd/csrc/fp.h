@@ -1,0 +1,413 @@
+// Prime-field arithmetic for the MSM kernels: Montgomery multiplication on signed, lazily
+// reduced limbs.  Replaces the reference's run-time generated wasm field module
+// (src/wasm/multiply-montgomery.ts:58-215, src/wasm/field-arithmetic.ts:32-166,
+// src/wasm/inverse.ts:191-218, src/field-msm.ts:86-123) for gfx950.
+//
+// Representation
+//   memory   : NW saturated 32-bit words, little endian ( = NW/2 64-bit limbs: 6x64 for the
+//              377/381-bit fields, 4x64 for the 255-bit fields).  Values in memory are
+//              Montgomery residues x*R mod p, *lazily* reduced: any value in [0, 3p).
+//   registers: N signed limbs of W bits (radix 2^W, R = 2^(N*W)); a value is sum l[j]*2^(W*j),
+//              limbs may be negative / wider than W bits between operations ("lazy").
+//
+// Why not saturated 64-bit-limb CIOS: on gfx950 v_mad_u64_u32, v_add_co_u32 and v_addc_co_u32
+// all issue at the same half rate (profiles/r01_ubench_int_instr_rates.txt), so every carry
+// instruction costs as much as a multiply.  With W = 28/29-bit limbs a whole column of products
+// is summed in one 64-bit accumulator by back-to-back v_mad_i64_i32 with no carry chain --
+// the same limb schedule idea as the reference's w=29 wasm code (multiply-montgomery.ts:47
+// `nSafeSteps`), and the CIOS variant is kept in fp_cios.h for the A/B measurement.
+//
+// Bounds (checked in tests/test_fp_model.py with the integer model of this file):
+//   mul/sqr inputs : |value| < 2^5 * p (2^3 * p for the 255-bit fields) and the limb magnitudes
+//                    A, B of the two operands satisfy  N*A*B + N*2^(2W) < 2^63
+//   mul/sqr output : value in (-1.5p, 0.5p), limbs 0..N-2 in [0, 2^W), top limb small signed.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define MSMZ_HD __host__ __device__ __forceinline__
+#else
+#define MSMZ_HD inline
+#endif
+
+namespace msmz {
+
+template <class F>
+struct Fe {
+  int32_t l[F::N];
+};
+
+template <class F>
+MSMZ_HD void fe_set_const(Fe<F>& r, const int32_t (&c)[F::N]) {
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = c[j];
+}
+
+template <class F>
+MSMZ_HD void fe_zero(Fe<F>& r) {
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = 0;
+}
+
+// r = a + b, limb-wise, no carry (field-arithmetic.ts:32-58 `add`, without its reduction)
+template <class F>
+MSMZ_HD void fe_add(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = a.l[j] + b.l[j];
+}
+
+// r = a - b, limb-wise, no borrow (field-arithmetic.ts:60-110 `subtract`; sign lives in the limbs)
+template <class F>
+MSMZ_HD void fe_sub(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = a.l[j] - b.l[j];
+}
+
+template <class F>
+MSMZ_HD void fe_neg(Fe<F>& r, const Fe<F>& a) {
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = -a.l[j];
+}
+
+// r = neg ? -a : a  (mask form, no divergence)
+template <class F>
+MSMZ_HD void fe_cneg(Fe<F>& r, const Fe<F>& a, uint32_t neg) {
+  int32_t m = -(int32_t)(neg & 1u);
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = (a.l[j] ^ m) - m;
+}
+
+// One parallel carry pass: limbs 0..N-2 come back within [0, 2^W + small), value unchanged.
+template <class F>
+MSMZ_HD void fe_carry(Fe<F>& a) {
+  constexpr int N = F::N, W = F::W;
+  constexpr int32_t MASK = (1 << W) - 1;
+  int32_t c[N];
+#pragma unroll
+  for (int j = 0; j < N - 1; j++) c[j] = a.l[j] >> W;
+#pragma unroll
+  for (int j = N - 2; j >= 1; j--) a.l[j] = (a.l[j] & MASK) + c[j - 1];
+  a.l[0] &= MASK;
+  a.l[N - 1] += c[N - 2];
+}
+
+// Full sequential carry: limbs 0..N-2 in [0, 2^W), top limb carries the sign.
+template <class F>
+MSMZ_HD void fe_normalize(Fe<F>& a) {
+  constexpr int N = F::N, W = F::W;
+  constexpr int32_t MASK = (1 << W) - 1;
+  int32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < N - 1; j++) {
+    int32_t t = a.l[j] + c;
+    a.l[j] = t & MASK;
+    c = t >> W;
+  }
+  a.l[N - 1] += c;
+}
+
+// Montgomery product r = a*b/R (mod p), product-scanning with one signed 64-bit column
+// accumulator (multiply-montgomery.ts:58-136, restated for signed lazy limbs).
+// Column k:  acc += sum_{i+j=k} a_i*b_j  -  sum_{i+j=k, j>=1} m_i*p_j ;  for k < N the new
+// quotient digit m_k = acc*p^-1 mod 2^W makes acc - m_k*p_0 divisible by 2^W.
+template <class F>
+MSMZ_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+  constexpr int N = F::N, W = F::W;
+  constexpr uint32_t MASK = (1u << W) - 1;
+  int32_t m[N];
+  int64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; k++) {
+    const int lo = k - (N - 1) > 0 ? k - (N - 1) : 0;
+    const int hi = k < N - 1 ? k : N - 1;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      const int j = k - i;
+      if (j >= 1 && F::PL[j] != 0) acc += (int64_t)m[i] * (int64_t)F::NPL[j];
+    }
+    if (k < N) {
+      uint32_t q = (uint32_t)acc;
+      if (F::PINV != 1u) q *= F::PINV;
+      m[k] = (int32_t)(q & MASK);
+      if (F::PL[0] != 1) acc += (int64_t)m[k] * (int64_t)F::NPL[0];
+      // with p_0 == 1 the low W bits of acc equal m_k and the floor shift drops them
+      acc >>= W;
+    } else {
+      r.l[k - N] = (int32_t)((uint32_t)acc & MASK);
+      acc >>= W;
+    }
+  }
+  r.l[N - 1] = (int32_t)acc;
+}
+
+// Montgomery square (multiply-montgomery.ts:138-215): off-diagonal products once, doubled.
+template <class F>
+MSMZ_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {
+  constexpr int N = F::N, W = F::W;
+  constexpr uint32_t MASK = (1u << W) - 1;
+  int32_t m[N], a2[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) a2[j] = a.l[j] * 2;
+  int64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; k++) {
+    const int lo = k - (N - 1) > 0 ? k - (N - 1) : 0;
+    const int hi = k < N - 1 ? k : N - 1;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      const int j = k - i;
+      if (i < j) acc += (int64_t)a2[i] * (int64_t)a.l[j];
+      if (i == j) acc += (int64_t)a.l[i] * (int64_t)a.l[i];
+    }
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      const int j = k - i;
+      if (j >= 1 && F::PL[j] != 0) acc += (int64_t)m[i] * (int64_t)F::NPL[j];
+    }
+    if (k < N) {
+      uint32_t q = (uint32_t)acc;
+      if (F::PINV != 1u) q *= F::PINV;
+      m[k] = (int32_t)(q & MASK);
+      if (F::PL[0] != 1) acc += (int64_t)m[k] * (int64_t)F::NPL[0];
+      acc >>= W;
+    } else {
+      r.l[k - N] = (int32_t)((uint32_t)acc & MASK);
+      acc >>= W;
+    }
+  }
+  r.l[N - 1] = (int32_t)acc;
+}
+
+// ---------------------------------------------------------------------------------- memory format
+// words (saturated, value in [0, 2^(32*NW))) -> normalized limbs.  (field-helpers.ts:211-266
+// `fromPackedBytes` does the same re-slicing from bytes to w-bit limbs.)
+template <class F>
+MSMZ_HD void fe_unpack(Fe<F>& r, const uint32_t* w) {
+  constexpr int N = F::N, W = F::W, NW = F::NW;
+  constexpr uint32_t MASK = (1u << W) - 1;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const int bit = W * j;
+    const int w0 = bit >> 5, sh = bit & 31;
+    uint32_t v = w[w0] >> sh;
+    if (sh + W > 32 && w0 + 1 < NW) v |= w[w0 + 1] << (32 - sh);
+    r.l[j] = (int32_t)(v & MASK);
+  }
+}
+
+// fully normalized, non-negative limbs (value < 2^(32*NW)) -> words
+template <class F>
+MSMZ_HD void fe_pack(uint32_t* w, const Fe<F>& a) {
+  constexpr int N = F::N, W = F::W, NW = F::NW;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    const int bit = 32 * i;
+    const int j0 = bit / W, o = bit - W * j0;
+    uint32_t v = (uint32_t)a.l[j0] >> o;
+    if (j0 + 1 < N) v |= (uint32_t)a.l[j0 + 1] << (W - o);
+    if (2 * W - o < 32 && j0 + 2 < N) v |= (uint32_t)a.l[j0 + 2] << (2 * W - o);
+    w[i] = v;
+  }
+}
+
+// Bring a lazy value |v| < 2^4 * p into [0, 3p) with normalized limbs: estimate the quotient
+// from the two top limbs, subtract q*p, one sequential carry.  (The reference instead keeps
+// everything in [0, 2p) with a conditional subtraction per operation: field-arithmetic.ts:112-166.)
+template <class F>
+MSMZ_HD void fe_reduce_small(Fe<F>& a) {
+  constexpr int N = F::N, W = F::W;
+  constexpr int64_t MASK = ((int64_t)1 << W) - 1;
+  // est ~ floor(v / 2^(W*(N-1))) within +-1
+  int32_t est = a.l[N - 1] + (a.l[N - 2] >> W);
+  // q ~ v/p - 1 (+-0.5): float divide of the top bits by the top bits of p (|est >> SH| < 2^24)
+  constexpr int SH = (F::PL[N - 1] >= (1 << 16)) ? 8 : 0;
+  float x = (float)(est >> SH) * (1.0f / (float)((F::PL[N - 1] >> SH) + 1));
+  int32_t q = (int32_t)__builtin_floorf(x) - 1;
+  // a -= q*p fused with the sequential carry (64-bit temporaries: q*p_j may exceed 32 bits)
+  int64_t c = 0;
+#pragma unroll
+  for (int j = 0; j < N - 1; j++) {
+    int64_t t = (int64_t)a.l[j] + c + (int64_t)q * (int64_t)F::NPL[j];
+    a.l[j] = (int32_t)(t & MASK);
+    c = t >> W;
+  }
+  a.l[N - 1] = (int32_t)((int64_t)a.l[N - 1] + c + (int64_t)q * (int64_t)F::NPL[N - 1]);
+}
+
+// store a lazy value (|v| < 2^4 p) as a memory-format residue in [0, 3p)
+template <class F>
+MSMZ_HD void fe_store(uint32_t* w, const Fe<F>& a) {
+  Fe<F> t = a;
+  fe_reduce_small(t);
+  fe_pack(w, t);
+}
+
+// store a direct mul/sqr output (value in (-1.5p, 0.5p)): add 2p, carry, pack
+template <class F>
+MSMZ_HD void fe_store_mulout(uint32_t* w, const Fe<F>& a) {
+  Fe<F> t;
+#pragma unroll
+  for (int j = 0; j < F::N; j++) t.l[j] = a.l[j] + F::P2[j];
+  fe_normalize(t);
+  fe_pack(w, t);
+}
+
+// ---------------------------------------------------------------------------------- canonical form
+// saturated-word helpers (used only off the hot path: inversion input, final outputs, equality)
+template <int NW>
+MSMZ_HD uint32_t words_sub(uint32_t* r, const uint32_t* a, const uint32_t* b) {  // returns borrow
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    uint64_t t = (uint64_t)a[i] - (uint64_t)b[i] - br;
+    r[i] = (uint32_t)t;
+    br = (t >> 32) & 1u;
+  }
+  return (uint32_t)br;
+}
+
+template <int NW>
+MSMZ_HD uint32_t words_add(uint32_t* r, const uint32_t* a, const uint32_t* b) {  // returns carry
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    uint64_t t = (uint64_t)a[i] + (uint64_t)b[i] + c;
+    r[i] = (uint32_t)t;
+    c = t >> 32;
+  }
+  return (uint32_t)c;
+}
+
+template <int NW>
+MSMZ_HD bool words_is_zero(const uint32_t* a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) o |= a[i];
+  return o == 0;
+}
+
+template <int NW>
+MSMZ_HD bool words_eq(const uint32_t* a, const uint32_t* b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) o |= a[i] ^ b[i];
+  return o == 0;
+}
+
+template <int NW>
+MSMZ_HD bool words_geq(const uint32_t* a, const uint32_t* b) {
+  uint32_t t[NW];
+  return words_sub<NW>(t, a, b) == 0;
+}
+
+// words (any value in [0, 4p)) -> canonical [0, p)   (field-arithmetic.ts:112-135 `reduce`)
+template <class F>
+MSMZ_HD void words_canon(uint32_t* w) {
+  constexpr int NW = F::NW;
+#pragma unroll 1
+  for (int it = 0; it < 3; it++) {
+    uint32_t t[NW];
+    uint32_t br = words_sub<NW>(t, w, F::PW);
+    if (!br) {
+#pragma unroll
+      for (int i = 0; i < NW; i++) w[i] = t[i];
+    }
+  }
+}
+
+// lazy register value -> canonical words in [0, p)
+template <class F>
+MSMZ_HD void fe_to_canon_words(uint32_t* w, const Fe<F>& a) {
+  fe_store<F>(w, a);
+  words_canon<F>(w);
+}
+
+template <class F>
+MSMZ_HD bool fe_is_zero_mod_p(const Fe<F>& a) {
+  uint32_t w[F::NW];
+  fe_to_canon_words<F>(w, a);
+  return words_is_zero<F::NW>(w);
+}
+
+// ---------------------------------------------------------------------------------- inversion
+// Binary extended Euclid on canonical words (the job of the reference's Kaliski almost-inverse,
+// inverse.ts:42-129 + 191-218).  Input and output are *Montgomery* residues: given a*R it
+// returns a^-1 * R.  Returns false (and r = 0) when the input is 0 mod p; the loop is bounded.
+template <class F>
+MSMZ_HD bool fe_inverse(Fe<F>& r, const Fe<F>& a) {
+  constexpr int NW = F::NW;
+  uint32_t u[NW], v[NW], x1[NW], x2[NW];
+  fe_to_canon_words<F>(u, a);
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    v[i] = F::PW[i];
+    x1[i] = (i == 0) ? 1u : 0u;
+    x2[i] = 0u;
+  }
+  if (words_is_zero<NW>(u)) {
+    fe_zero(r);
+    return false;
+  }
+  // invariant: x1 * a0 = u, x2 * a0 = v (mod p); u, v > 0; one of them reaches 1
+  auto halve_mod = [](uint32_t* x) {
+    uint32_t carry = 0;
+    if (x[0] & 1u) carry = words_add<NW>(x, x, F::PW);
+#pragma unroll
+    for (int i = 0; i < NW - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+    x[NW - 1] = (x[NW - 1] >> 1) | (carry << 31);
+  };
+  auto halve = [](uint32_t* x) {
+#pragma unroll
+    for (int i = 0; i < NW - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+    x[NW - 1] >>= 1;
+  };
+  auto is_one = [](const uint32_t* x) {
+    uint32_t o = x[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < NW; i++) o |= x[i];
+    return o == 0;
+  };
+#pragma unroll 1
+  for (int it = 0; it < 4 * F::BITS + 8; it++) {
+    if (is_one(u) || is_one(v)) break;
+    if (!(u[0] & 1u)) {
+      halve(u);
+      halve_mod(x1);
+    } else if (!(v[0] & 1u)) {
+      halve(v);
+      halve_mod(x2);
+    } else if (words_geq<NW>(u, v)) {
+      words_sub<NW>(u, u, v);
+      if (words_sub<NW>(x1, x1, x2)) words_add<NW>(x1, x1, F::PW);
+    } else {
+      words_sub<NW>(v, v, u);
+      if (words_sub<NW>(x2, x2, x1)) words_add<NW>(x2, x2, F::PW);
+    }
+  }
+  const uint32_t* res = is_one(u) ? x1 : x2;
+  Fe<F> t, r3;
+  fe_unpack<F>(t, res);           // (a R)^-1 = a^-1 R^-1
+  fe_set_const<F>(r3, F::R3);
+  fe_mul<F>(r, t, r3);            // * R^3 / R  ->  a^-1 R
+  return true;
+}
+
+// to / from Montgomery form (field-msm.ts:183-185 `toMontgomery` = multiply by R^2)
+template <class F>
+MSMZ_HD void fe_to_mont(Fe<F>& r, const Fe<F>& a) {
+  Fe<F> r2;
+  fe_set_const<F>(r2, F::R2);
+  fe_mul<F>(r, a, r2);
+}
+
+template <class F>
+MSMZ_HD void fe_from_mont(Fe<F>& r, const Fe<F>& a) {
+  Fe<F> one;
+  fe_zero(one);
+  one.l[0] = 1;
+  fe_mul<F>(r, a, one);
+}
+
+}  // namespace msmz

@@ -1,0 +1,579 @@
+// HIP kernels of the Pippenger MSM pipeline (gfx950, wave64).  One kernel family per row of the
+// hot-path table:
+//
+//   k_points_to_mont     upload: canonical bytes -> lazy Montgomery residues (+ endomorphism copy)
+//                        (parallel.ts:97-112 pointsFromBytes, field-msm.ts:183-185, wasm/curve.ts:90-103)
+//   k_digits             GLV split + signed c-bit digits + bucket histogram
+//                        (msm-batched-affine.ts:149,172-200; scalar-glv.ts:105-128)
+//   k_scan_*             exclusive prefix sums: bucket offsets and per-round pair offsets
+//                        (msm-batched-affine.ts:411-435 integrateBucketCounts)
+//   k_scatter            counting-sort scatter of point *indices* into bucket order
+//                        (msm-batched-affine.ts:444-490 sortPoints -- which copies 116-byte points;
+//                        here 4-byte references are scattered and points are gathered on first use)
+//   k_batch_add          one tree round of batched-affine additions inside all buckets, with a
+//                        workgroup-wide Montgomery batch inversion (product tree in LDS, one field
+//                        inversion per workgroup)
+//                        (msm-batched-affine.ts:232-270; curve-affine.ts:376-522; inverse.ts:220-271)
+//   k_reduce_first/next  bucket reduction  sum_l l*B_l  by grouped running sums in XYZZ coordinates
+//                        (msm-batched-affine.ts:544-571 reduceBucketsColumnProjective)
+//
+// Bucket numbering: global bucket g = k*L + (l-1) for window k and digit l in [1, L], L = 2^(c-1).
+// Sorted references: ref = point_index | (negate << 31).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "constants_gen.h"
+#include "curve.h"
+#include "scalar.h"
+
+namespace msmz {
+
+constexpr uint32_t REF_NEG = 0x80000000u;
+constexpr uint32_t REF_IDX = 0x7fffffffu;
+
+struct MsmMeta {               // small device-resident block of run-time totals
+  uint32_t max_bucket;         // largest bucket size
+  uint32_t n_entries;          // E = number of non-zero digits = point additions' inputs
+  uint32_t error;              // bit 0: zero denominator hit in the unsafe batch add
+  uint32_t pad;
+  uint32_t round_pairs[32];    // number of pairs in tree round r
+};
+
+// ------------------------------------------------------------------------------------------------ loads
+template <class F>
+__device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src) {
+  // records are 16-byte aligned: 2*NW words = 96 B / 64 B
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+  for (int i = 0; i < (2 * F::NW) / 4; i++) {
+    uint4 v = s4[i];
+    dst[4 * i] = v.x;
+    dst[4 * i + 1] = v.y;
+    dst[4 * i + 2] = v.z;
+    dst[4 * i + 3] = v.w;
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void store_words(uint32_t* dst, const uint32_t* src) {
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+  for (int i = 0; i < (2 * F::NW) / 4; i++) d4[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+}
+
+// load an affine point record; returns true if it is the point at infinity
+template <class F>
+__device__ __forceinline__ bool load_affine(Affine<F>& p, const uint32_t* rec, uint32_t negate) {
+  uint32_t w[2 * F::NW];
+  load_words<F>(w, rec);
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 2 * F::NW; i++) o |= w[i];
+  fe_unpack<F>(p.x, w);
+  Fe<F> y;
+  fe_unpack<F>(y, w + F::NW);
+  fe_cneg(p.y, y, negate);
+  return o == 0;
+}
+
+template <class F>
+__device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, bool inf) {
+  uint32_t w[2 * F::NW];
+  if (inf) {
+#pragma unroll
+    for (int i = 0; i < 2 * F::NW; i++) w[i] = 0;
+  } else {
+    fe_store<F>(w, p.x);
+    fe_store<F>(w + F::NW, p.y);
+    // a finite point can never serialize to the all-zero record: x = y = 0 is not on the curve
+  }
+  store_words<F>(rec, w);
+}
+
+template <class F>
+__device__ __forceinline__ void load_xyzz(Xyzz<F>& p, const uint32_t* rec) {
+  uint32_t w[2 * F::NW];
+  load_words<F>(w, rec);
+  fe_unpack<F>(p.X, w);
+  fe_unpack<F>(p.Y, w + F::NW);
+  load_words<F>(w, rec + 2 * F::NW);
+  fe_unpack<F>(p.ZZ, w);
+  fe_unpack<F>(p.ZZZ, w + F::NW);
+}
+
+template <class F>
+__device__ __forceinline__ void store_xyzz(uint32_t* rec, const Xyzz<F>& p) {
+  uint32_t w[2 * F::NW];
+  fe_store<F>(w, p.X);
+  fe_store<F>(w + F::NW, p.Y);
+  store_words<F>(rec, w);
+  fe_store<F>(w, p.ZZ);
+  fe_store<F>(w + F::NW, p.ZZZ);
+  store_words<F>(rec + 2 * F::NW, w);
+}
+
+// ------------------------------------------------------------------------------------------------ upload
+// in : n records of 2*NW canonical little-endian words (x | y), optional infinity flags
+// out: n records in memory format; with `endo`, records [n, 2n) hold (beta*x, y)
+template <class F>
+__global__ void __launch_bounds__(256) k_points_to_mont(uint32_t* out, const uint32_t* in, const uint8_t* is_inf,
+                                                        uint32_t n, int endo) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p, m;
+  bool inf = load_affine<F>(p, in + (size_t)i * 2 * F::NW, 0);
+  (void)inf;
+  bool flagged = is_inf != nullptr && is_inf[i] != 0;
+  fe_to_mont(m.x, p.x);
+  fe_to_mont(m.y, p.y);
+  store_affine<F>(out + (size_t)i * 2 * F::NW, m, flagged);
+  if (endo) {
+    Fe<F> beta, bx;
+    fe_set_const<F>(beta, F::BETA);
+    fe_mul(bx, m.x, beta);
+    m.x = bx;
+    store_affine<F>(out + ((size_t)n + i) * 2 * F::NW, m, flagged);
+  }
+}
+
+// memory-format records -> canonical affine words (for downloads / tests)
+template <class F>
+__global__ void __launch_bounds__(256) k_points_from_mont(uint32_t* out, const uint32_t* in, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p;
+  bool inf = load_affine<F>(p, in + (size_t)i * 2 * F::NW, 0);
+  uint32_t w[2 * F::NW];
+  if (inf) {
+#pragma unroll
+    for (int j = 0; j < 2 * F::NW; j++) w[j] = 0;
+  } else {
+    Fe<F> t;
+    fe_from_mont(t, p.x);
+    fe_to_canon_words<F>(w, t);
+    fe_from_mont(t, p.y);
+    fe_to_canon_words<F>(w + F::NW, t);
+  }
+  store_words<F>(out + (size_t)i * 2 * F::NW, w);
+}
+
+// ------------------------------------------------------------------------------------------------ digits
+// digits[k*M + i] for i in [0, M): M = N (no GLV) or 2N (GLV: entry N+i is the endomorphism half).
+template <class Fr, bool GLV>
+__global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* counts, const uint32_t* scalars,
+                                                uint32_t n, int c, int K) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t L = 1u << (c - 1);
+  const uint32_t M = GLV ? 2 * n : n;
+  uint32_t s[8];
+  {
+    const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 a = p4[0], b = p4[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  }
+  if (GLV) {
+    uint32_t h[2][4], neg[2];
+    glv_decompose<Fr>(h[0], h[1], neg[0], neg[1], s);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      uint32_t carry = 0;
+      for (int k = 0; k < K; k++) {
+        uint32_t l = extract_bits<4>(h[half], k * c, c) + carry;
+        if (l > L) {
+          l = 2 * L - l;
+          carry = 1;
+        } else {
+          carry = 0;
+        }
+        // the half scalar's own sign flips every digit's sign
+        uint32_t ng = (carry ^ neg[half]) & (l != 0 ? 1u : 0u);
+        digits[(size_t)k * M + (size_t)half * n + i] = l | (ng << 31);
+        if (l != 0) atomicAdd(&counts[(size_t)k * L + (l - 1)], 1u);
+      }
+    }
+  } else {
+    uint32_t carry = 0;
+    for (int k = 0; k < K; k++) {
+      uint32_t l = extract_bits<8>(s, k * c, c) + carry;
+      if (l > L) {
+        l = 2 * L - l;
+        carry = 1;
+      } else {
+        carry = 0;
+      }
+      digits[(size_t)k * M + i] = l | (carry << 31);
+      if (l != 0) atomicAdd(&counts[(size_t)k * L + (l - 1)], 1u);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ scans
+// Exclusive scan of n values v(g) in three launches; out has n + 1 entries (out[n] = total).
+//   mode 0: v(g) = in[g]                                   (bucket sizes -> offsets)
+//   mode 1: v(g) = pairs in round r of bucket g, r = blockIdx.y, from bucket offsets `in`
+//           pairs_m(s) = floor((s + m - 1) / (2m)), m = 2^r  (number of j with j*2m + m < s)
+constexpr int SCAN_T = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t scan_value(const uint32_t* in, uint32_t g, uint32_t n, int mode, int r) {
+  if (g >= n) return 0;
+  if (mode == 0) return in[g];
+  uint32_t s = in[g + 1] - in[g];
+  uint32_t m = 1u << r;
+  return (s + m - 1) >> (r + 1);
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* lds) {
+  // 256 threads: wave-level inclusive scan by shuffles, then across the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_T / 64; w++) {
+    uint32_t t = lds[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_partials(uint32_t* partials, const uint32_t* in, uint32_t n, int mode,
+                                                          uint32_t nblocks) {
+  __shared__ uint32_t lds[SCAN_T / 64];
+  const int r = blockIdx.y;
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) sum += scan_value(in, base + j, n, mode, r);
+  uint32_t total;
+  block_exclusive_scan(sum, &total, lds);
+  if (threadIdx.x == 0) partials[(size_t)r * nblocks + blockIdx.x] = total;
+}
+
+// one block per round: exclusive scan of the per-tile partials (in place); writes the grand total
+__global__ void __launch_bounds__(SCAN_T) k_scan_top(uint32_t* partials, uint32_t nblocks, uint32_t* totals) {
+  __shared__ uint32_t lds[SCAN_T / 64];
+  const int r = blockIdx.x;
+  uint32_t* p = partials + (size_t)r * nblocks;
+  uint32_t running = 0;
+  for (uint32_t start = 0; start < nblocks; start += SCAN_T) {
+    uint32_t idx = start + threadIdx.x;
+    uint32_t v = idx < nblocks ? p[idx] : 0;
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(v, &total, lds);
+    if (idx < nblocks) p[idx] = running + ex;
+    running += total;
+  }
+  if (threadIdx.x == 0) totals[r] = running;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_apply(uint32_t* out, const uint32_t* partials, const uint32_t* in,
+                                                       uint32_t n, int mode, uint32_t nblocks, size_t out_stride,
+                                                       uint32_t* max_out) {
+  __shared__ uint32_t lds[SCAN_T / 64];
+  const int r = blockIdx.y;
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], sum = 0, mx = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    v[j] = scan_value(in, base + j, n, mode, r);
+    sum += v[j];
+    mx = v[j] > mx ? v[j] : mx;
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(sum, &total, lds) + partials[(size_t)r * nblocks + blockIdx.x];
+  uint32_t* o = out + (size_t)r * out_stride;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    if (base + j < n) o[base + j] = ex;
+    ex += v[j];
+    if (base + j + 1 == n) o[n] = ex;
+  }
+  if (max_out != nullptr && mx != 0) atomicMax(max_out, mx);
+}
+
+// ------------------------------------------------------------------------------------------------ scatter
+// refs[off[g] + (arrival order within bucket g)] = i | negate<<31  for every non-zero digit.
+// (This is the HBM-bound "bucket scatter": algorithmic bytes = 4 B digit read + 4 B reference write
+// per entry)
+__global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t* cursor, const uint32_t* off,
+                                                 const uint32_t* digits, uint32_t M, int c) {
+  constexpr int ITEMS = 4;
+  const uint32_t L = 1u << (c - 1);
+  const uint32_t k = blockIdx.y;
+  const uint32_t* dk = digits + (size_t)k * M;
+  const uint32_t base = blockIdx.x * (256 * ITEMS) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    uint32_t i = base + j * 256;
+    if (i >= M) break;
+    uint32_t d = dk[i];
+    uint32_t l = d & REF_IDX;
+    if (l == 0) continue;
+    uint32_t g = k * L + (l - 1);
+    uint32_t pos = off[g] + atomicAdd(&cursor[g], 1u);
+    refs[pos] = i | (d & REF_NEG);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ batch add
+// Round r (m = 2^r) of the in-bucket pair tree: inside each bucket (positions relative to its start)
+// element j*2m + m is added into element j*2m, for every j with j*2m + m < size -- exactly the
+// reference's schedule (msm-batched-affine.ts:232-247).  Sums live in `slots`, one record per sorted
+// position, written in place from round 0 on; round 0 gathers the original points through `refs`.
+//
+// One thread = one pair.  The workgroup inverts all its x-differences together: leaves of a product
+// tree in LDS, up-sweep, ONE field inversion (wave 0, all lanes on the same value -> no divergence),
+// down-sweep.  3 products per element for the inversion + 3 for the affine addition.
+//
+// SAFE handles infinity operands, equal points (doubling, denominator 2y) and opposite points
+// (result infinity) like batchAddNew (curve-affine.ts:376-458); the unsafe variant assumes distinct
+// x like batchAddUnsafeNew (:463-522) and raises meta->error if a zero denominator poisons a batch.
+template <class F, int T, bool SAFE>
+__global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
+                                                 const uint32_t* off, const uint32_t* rscan, uint32_t nb, int r,
+                                                 MsmMeta* meta) {
+  constexpr int N = F::N;
+  constexpr int RW = 2 * F::NW;          // record words
+  // product tree: level d has T >> d nodes, stored limb-major; level offsets 0, T, T + T/2, ...
+  __shared__ int32_t tree[N * 2 * T];
+  const uint32_t total = meta->round_pairs[r];
+  const uint32_t t = blockIdx.x * T + threadIdx.x;
+  const bool active = t < total;
+  const uint32_t m = 1u << r;
+
+  Affine<F> p1, p2;
+  Fe<F> leaf;
+  uint32_t posA = 0;
+  int kind = 0;   // 0 = inactive, 1 = add, 2 = double, 3 = result is p1, 4 = result is p2, 5 = result infinity
+  fe_set_const<F>(leaf, F::ONE);
+  if (active) {
+    // bucket of pair t: largest g with rscan[g] <= t
+    uint32_t lo = 0, hi = nb;   // invariant rscan[lo] <= t < rscan[hi]
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (rscan[mid] <= t) lo = mid; else hi = mid;
+    }
+    const uint32_t g = lo;
+    const uint32_t start = off[g], size = off[g + 1] - start;
+    const uint32_t a = (t - rscan[g]) * 2 * m, b = a + m;
+    posA = start + a;
+    const uint32_t posB = start + b;
+    bool infA, infB;
+    if (r == 0) {
+      uint32_t ra = refs[posA], rb = refs[posB];
+      infA = load_affine<F>(p1, points + (size_t)(ra & REF_IDX) * RW, ra >> 31);
+      infB = load_affine<F>(p2, points + (size_t)(rb & REF_IDX) * RW, rb >> 31);
+    } else {
+      infA = load_affine<F>(p1, slots + (size_t)posA * RW, 0);
+      if (b + 1 < size) {
+        infB = load_affine<F>(p2, slots + (size_t)posB * RW, 0);
+      } else {   // last element of the bucket was never paired: still the original point
+        uint32_t rb = refs[posB];
+        infB = load_affine<F>(p2, points + (size_t)(rb & REF_IDX) * RW, rb >> 31);
+      }
+    }
+    kind = 1;
+    fe_sub(leaf, p2.x, p1.x);
+    if (SAFE) {
+      if (infA) {
+        kind = 4;
+      } else if (infB) {
+        kind = 3;
+      } else if (fe_is_zero(leaf)) {
+        Fe<F> dy;
+        fe_sub(dy, p2.y, p1.y);
+        if (fe_is_zero(dy) && !fe_is_zero(p1.y)) {
+          kind = 2;
+          fe_add(leaf, p1.y, p1.y);
+        } else {
+          kind = 5;
+        }
+      }
+      if (kind >= 3) fe_set_const<F>(leaf, F::ONE);
+    }
+  }
+
+  // ---- leaves
+#pragma unroll
+  for (int j = 0; j < N; j++) tree[j * 2 * T + threadIdx.x] = leaf.l[j];
+  __syncthreads();
+  // ---- up-sweep: node(d+1, i) = node(d, 2i) * node(d, 2i+1)
+  int lvl_off = 0;
+#pragma unroll 1
+  for (int width = T >> 1; width >= 1; width >>= 1) {
+    const int child_off = lvl_off;
+    lvl_off += width * 2;
+    if ((int)threadIdx.x < width) {
+      Fe<F> x, y, z;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        x.l[j] = tree[j * 2 * T + child_off + 2 * threadIdx.x];
+        y.l[j] = tree[j * 2 * T + child_off + 2 * threadIdx.x + 1];
+      }
+      fe_mul(z, x, y);
+#pragma unroll
+      for (int j = 0; j < N; j++) tree[j * 2 * T + lvl_off + threadIdx.x] = z.l[j];
+    }
+    __syncthreads();
+  }
+  // ---- root inversion (lvl_off now addresses the single root node)
+  if (threadIdx.x < 64) {
+    Fe<F> root, inv;
+#pragma unroll
+    for (int j = 0; j < N; j++) root.l[j] = tree[j * 2 * T + lvl_off];
+    bool ok = fe_inverse(inv, root);
+    if (threadIdx.x == 0) {
+      if (!ok) atomicOr(&meta->error, 1u);
+#pragma unroll
+      for (int j = 0; j < N; j++) tree[j * 2 * T + lvl_off] = inv.l[j];
+    }
+  }
+  __syncthreads();
+  // ---- down-sweep: inv(left) = inv(parent) * right, inv(right) = inv(parent) * left
+#pragma unroll 1
+  for (int width = 1; width <= T >> 1; width <<= 1) {
+    const int parent_off = lvl_off;
+    lvl_off -= width * 2;
+    if ((int)threadIdx.x < width) {
+      Fe<F> pi, x, y, xi, yi;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        pi.l[j] = tree[j * 2 * T + parent_off + threadIdx.x];
+        x.l[j] = tree[j * 2 * T + lvl_off + 2 * threadIdx.x];
+        y.l[j] = tree[j * 2 * T + lvl_off + 2 * threadIdx.x + 1];
+      }
+      fe_mul(xi, pi, y);
+      fe_mul(yi, pi, x);
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        tree[j * 2 * T + lvl_off + 2 * threadIdx.x] = xi.l[j];
+        tree[j * 2 * T + lvl_off + 2 * threadIdx.x + 1] = yi.l[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  Fe<F> inv;
+#pragma unroll
+  for (int j = 0; j < N; j++) inv.l[j] = tree[j * 2 * T + threadIdx.x];
+
+  Affine<F> res;
+  bool res_inf = false;
+  if (!SAFE || kind == 1) {
+    affine_add_with_inv(res, p1, p2, inv);
+  } else if (kind == 2) {
+    affine_double_with_inv(res, p1, inv);
+  } else if (kind == 3) {
+    res = p1;
+  } else if (kind == 4) {
+    res = p2;
+  } else {
+    res_inf = true;
+  }
+  store_affine<F>(slots + (size_t)posA * RW, res, res_inf);
+}
+
+// ------------------------------------------------------------------------------------------------ reduce
+// Bucket sum of global bucket g after all tree rounds: empty -> infinity; one element -> the original
+// point; otherwise slot[off[g]].
+template <class F>
+__device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const uint32_t* slots, const uint32_t* points,
+                                                const uint32_t* refs, const uint32_t* off) {
+  constexpr int RW = 2 * F::NW;
+  uint32_t start = off[g], size = off[g + 1] - start;
+  if (size == 0) return true;
+  if (size == 1) {
+    uint32_t rf = refs[start];
+    return load_affine<F>(p, points + (size_t)(rf & REF_IDX) * RW, rf >> 31);
+  }
+  return load_affine<F>(p, slots + (size_t)start * RW, 0);
+}
+
+// Level 1.  Window k's buckets (0-based index i = l - 1 in [0, L)) are cut into groups of S; group a
+// yields   row_a = sum_b B[aS + b]   and   tri_a = sum_b b * B[aS + b]   by the running-sum trick
+// (msm-batched-affine.ts:556-559), so that   sum_i i*B_i = sum_a tri_a + S * sum_a a * row_a.
+// rows/tris: XYZZ records (4*NW words) indexed [k * groups + a].
+template <class F>
+__global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
+                                                      const uint32_t* points, const uint32_t* refs, const uint32_t* off,
+                                                      uint32_t L, uint32_t S, uint32_t groups, uint32_t total) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  uint32_t k = t / groups, a = t - k * groups;
+  uint32_t g0 = k * L + a * S;
+  Xyzz<F> run, tri;
+  xyzz_set_inf(run);
+  xyzz_set_inf(tri);
+  for (uint32_t b = S; b-- > 1;) {
+    Affine<F> p;
+    bool inf = (a * S + b >= L) ? true : load_bucket_sum<F>(p, g0 + b, slots, points, refs, off);
+    Xyzz<F> tmp;
+    xyzz_madd(tmp, run, p, inf);
+    run = tmp;
+    xyzz_add(tmp, tri, run);
+    tri = tmp;
+  }
+  {
+    Affine<F> p;
+    bool inf = load_bucket_sum<F>(p, g0, slots, points, refs, off);
+    Xyzz<F> tmp;
+    xyzz_madd(tmp, run, p, inf);
+    run = tmp;
+  }
+  store_xyzz<F>(rows + (size_t)t * 4 * F::NW, run);
+  store_xyzz<F>(tris + (size_t)t * 4 * F::NW, tri);
+}
+
+// Level >= 2 on XYZZ inputs: for group A of S consecutive entries (per window, n_in entries):
+//   row'_A = sum_b row[AS+b],  tri'_A = sum_b b*row[AS+b],  C'_A = sum_b C[AS+b] + 2^shift * tri'_A
+// where 2^shift is the product of all previous group sizes.  After the last level (one entry per
+// window)  sum_i i*B_i = C  and  sum_i B_i = row.
+template <class F>
+__global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+                                                     const uint32_t* c_in, uint32_t n_in, uint32_t S, uint32_t groups,
+                                                     uint32_t total, int shift) {
+  constexpr int XW = 4 * F::NW;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  uint32_t k = t / groups, A = t - k * groups;
+  size_t base = (size_t)k * n_in + (size_t)A * S;
+  Xyzz<F> run, tri, cs, tmp, p;
+  xyzz_set_inf(run);
+  xyzz_set_inf(tri);
+  xyzz_set_inf(cs);
+  for (uint32_t b = S; b-- > 0;) {
+    if (A * S + b >= n_in) continue;
+    load_xyzz<F>(p, c_in + (base + b) * XW);
+    xyzz_add(tmp, cs, p);
+    cs = tmp;
+    load_xyzz<F>(p, rows_in + (base + b) * XW);
+    xyzz_add(tmp, run, p);
+    run = tmp;
+    if (b >= 1) {
+      xyzz_add(tmp, tri, run);
+      tri = tmp;
+    }
+  }
+  // note: tri accumulated run after including entry b, for b >= 1  ->  sum_b b*row_b
+  for (int s = 0; s < shift; s++) {
+    xyzz_dbl(tmp, tri);
+    tri = tmp;
+  }
+  xyzz_add(tmp, cs, tri);
+  store_xyzz<F>(rows_out + (size_t)t * XW, run);
+  store_xyzz<F>(c_out + (size_t)t * XW, tmp);
+}
+
+}  // namespace msmz
