@@ -109,7 +109,7 @@ class Engine : public IEngine {
     MSMZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     for (auto& e : ev_) MSMZ_HIP(hipEventCreate(&e));
     MSMZ_HIP(hipHostMalloc(&h_meta_, sizeof(MsmMeta)));
-    MSMZ_HIP(hipHostMalloc(&h_final_, (size_t)2 * 64 * XW * 4));
+    MSMZ_HIP(hipHostMalloc(&h_final_, (size_t)2 * kMaxWindows * XW * 4));
     return meta_.ensure(sizeof(MsmMeta));
   }
 
@@ -292,7 +292,7 @@ class Engine : public IEngine {
     const int K = (b + 1 + c - 1) / c;                    // msm-batched-affine.ts:96
     const uint32_t L = 1u << (c - 1);
     const uint64_t nb64 = (uint64_t)K * L;
-    if (nb64 + 1 >= (1ull << 31) || (uint64_t)K * M >= (1ull << 31) || K > 64) return MSMZ_ERR_ARG;
+    if (nb64 + 1 >= (1ull << 31) || (uint64_t)K * M >= (1ull << 31) || K > kMaxWindows) return MSMZ_ERR_ARG;
     const uint32_t nb = (uint32_t)nb64;
     const bool timing = opt.timing != 0;
     int ei = 0;
@@ -407,7 +407,7 @@ class Engine : public IEngine {
     mark();  // reduce end
     MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipMemcpyAsync(h_final_, red_[cur * 2].p, (size_t)K * XW * 4, hipMemcpyDeviceToHost, stream_));
-    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)64 * XW, red_[cur * 2 + 1].p, (size_t)K * XW * 4,
+    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * XW, red_[cur * 2 + 1].p, (size_t)K * XW * 4,
                             hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
@@ -426,7 +426,7 @@ class Engine : public IEngine {
         }
       Xyzz<F> row, cc, w, t;
       host_load_xyzz(row, h_final_ + (size_t)k * XW);
-      host_load_xyzz(cc, h_final_ + (size_t)(64 + k) * XW);
+      host_load_xyzz(cc, h_final_ + (size_t)(kMaxWindows + k) * XW);
       xyzz_add(w, row, cc);
       xyzz_add(t, acc, w);
       acc = t;
@@ -547,6 +547,7 @@ class Engine : public IEngine {
 
   // shared state -------------------------------------------------------------------------------
   static constexpr int kMaxEvents = 64;
+  static constexpr int kMaxWindows = 128;
   int device_;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[kMaxEvents] = {};

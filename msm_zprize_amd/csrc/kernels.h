@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t
   Affine<F> p1, p2;
   Fe<F> leaf;
   uint32_t posA = 0;
+  bool inf_b = false;
   int kind = 0;   // 0 = inactive, 1 = add, 2 = double, 3 = result is p1, 4 = result is p2, 5 = result infinity
   fe_set_const<F>(leaf, F::ONE);
   if (active) {
@@ -385,6 +386,7 @@ __global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t
       }
     }
     kind = 1;
+    inf_b = infB;
     fe_sub(leaf, p2.x, p1.x);
     if (SAFE) {
       if (infA) {
@@ -479,6 +481,7 @@ __global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t
     res = p1;
   } else if (kind == 4) {
     res = p2;
+    res_inf = inf_b;   // infinity + infinity stays the all-zero record
   } else {
     res_inf = true;
   }
