@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the MSM hot path.  `python bench.py --gpus N --steps K --warmup W`
+
+A step = one MSM over one batch of fresh synthetic scalars; points and scalars are resident in HBM
+when the timed region starts (the reference keeps its points resident and times only the msm call:
+scripts/msm-weierstrass.ts:19-35).  N = 1 runs BASELINE.json configs[1] (BLS12-377 G1, 2^20, no GLV,
+affine buckets); N > 1 runs configs[4]'s sharding (2^23 points per GPU, 2^26 at N = 8): every rank
+owns a contiguous input shard, runs the whole single-GPU pipeline on it, and the N partial sums are
+gathered (RCCL all_gather of 100-byte records) and added on the host -- no data-path collective.
+
+Prints ONE JSON line (rank 0).  value = non-zero signed digits (= bucket insertions, "point-adds",
+SURVEY.md section 8d) of all ranks per second.
+"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=0, help="log2 of points PER GPU (default 20 at 1 GPU, 23 otherwise)")
+    ap.add_argument("--glv", type=int, default=0)
+    ap.add_argument("--c", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2n", type=int, default=17)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the MSM has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import msm_zprize_amd as m
+    from msm_zprize_amd.curves import bls12377Params as params
+
+    log2n = args.log2n or (20 if world == 1 else 23)
+    n = 1 << log2n
+    m.startThreads(device=local_rank)
+    curve = m.Weierstrass.create(params)
+    par = curve.Parallel
+    seed = 0x6D736D7A + 1   # config index 1
+    # shard = contiguous index range [rank*n, (rank+1)*n): generator index is global via the seed offset
+    points = par.randomPointsFast(n, seed + 1000003 * rank)
+    nsets = args.steps + args.warmup
+    scalar_sets = [par.randomScalars(n, seed + 7919 * (s + 1) + 1000003 * rank) for s in range(nsets)]
+    opts = {"glv": args.glv, "c": args.c}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(s, verbose=True):
+        out = par.msmUnsafe(scalar_sets[s], points, n, verbose, opts)
+        res = out["result"]
+        if world > 1:
+            # exchange step: gather the per-GPU partial sums, add on the host
+            fb = curve.fe_bytes
+            rec = res["x"].to_bytes(fb, "little") + res["y"].to_bytes(fb, "little") + bytes([1 if res["isZero"] else 0]) + bytes(3)
+            t = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+            gathered = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            total = {"x": 0, "y": 1, "isZero": True}
+            for g in gathered:
+                b = bytes(g.cpu().numpy())
+                p = {"x": int.from_bytes(b[:fb], "little"), "y": int.from_bytes(b[fb:2 * fb], "little"), "isZero": b[2 * fb] != 0}
+                total = curve.pointAdd(total, p)
+            res = total
+        return out, res
+
+    for s in range(args.warmup):
+        one_step(s)
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for s in range(args.warmup, nsets):
+        out, _ = one_step(s)
+        stats.append(out["stats"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    entries = torch.tensor([float(sum(int(st.n_entries) for st in stats))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(entries, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    total_entries = float(entries.item())
+
+    if rank == 0:
+        st0 = stats[-1]
+        K, c = st0.K, st0.c
+        M = n * (2 if args.glv else 1)
+        ms_per_step = elapsed / args.steps * 1e3
+        # roofline of the HBM-bound kernel the north_star names: the bucket scatter.  Algorithmic bytes
+        # per launch = M*K*(4 B digit read + 4 B reference write); duration from HIP
+        # events recorded on the library's own stream around that kernel, averaged over the timed steps.
+        scatter_ms = statistics.mean(float(s.scatter_kernel_ms) for s in stats)
+        scatter_bytes = M * K * 8
+        achieved = scatter_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
+        acc_ms = statistics.mean(float(s.stage_ms[4]) for s in stats)
+        pairs = statistics.mean(float(s.n_pairs) for s in stats)
+        result = {
+            "metric": "Mpoint-adds/s (ms per MSM in ms_per_step)",
+            "value": total_entries / elapsed / 1e6,
+            "unit": "Mpoint-adds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (28-bit lazy Montgomery, i64 accumulate)", "data": "synthetic",
+            "config": {"workload": f"BLS12-377 G1 MSM 2^{log2n} per GPU x {world} GPU, "
+                                   f"{'GLV' if args.glv else 'no GLV'}, affine buckets (batched-affine), msmUnsafe",
+                       "log2n_per_gpu": log2n, "c": c, "K": K, "glv": bool(args.glv),
+                       "point_adds_per_msm": total_entries / args.steps / world, "sharding": f"input-split x{world}"},
+            "roofline": {"kernel": "k_scatter", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "bytes_per_launch": scatter_bytes, "avg_launch_ms": scatter_ms},
+            "valu_roofline": {"kernel": "k_batch_add (all rounds)", "bound": "int32 VALU (v_mad_i64_i32)",
+                              "achieved": pairs * 6 / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
+                              "peak": 72.0, "unit": "Gmodmul/s",
+                              "note": "6 field mults per affine add; peak = measured fe_mul loop (profiles/r01_ubench_fp_modmul.txt)",
+                              "avg_ms": acc_ms},
+            "stage_ms": {name: statistics.mean(float(s.stage_ms[i]) for s in stats)
+                         for i, name in enumerate(["digits", "scan", "scatter", "plan", "accumulate", "reduce", "final", "total"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(params, args.cpu_log2n)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(params, log2n):
+    """The oracle's C restatement of src/bigint/msm.ts timed on this host's cores, on a bounded sample
+    (2^log2n points of the same distribution).  A reported baseline, not the target."""
+    from oracle import c_oracle
+    from oracle import params as OP
+    import msm_zprize_amd as m
+    oparams = OP.CURVES[params["label"]]
+    n = 1 << log2n
+    curve = m.Weierstrass.create(params)
+    pts = curve.Parallel.randomPointsFast(n, 99)
+    sc = curve.Parallel.randomScalars(n, 99)
+    fb = curve.fe_bytes
+    pbuf = ctypes.create_string_buffer(2 * fb * n)
+    sbuf = ctypes.create_string_buffer(32 * n)
+    from msm_zprize_amd import _native
+    _native.check(_native.lib().msmz_download_points(curve._ctx, pts.handle, 0, n, pbuf, None), "download")
+    _native.check(_native.lib().msmz_download_scalars(curve._ctx, sc.handle, 0, n, sbuf), "download")
+    threads = min(c_oracle.lib().oracle_num_threads(), os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    res, adds = c_oracle.msm_bytes(oparams, sbuf.raw, pbuf.raw, n, None, threads)
+    dt = time.perf_counter() - t0
+    gpu = curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"]
+    curve.close()
+    return {"value": adds / dt / 1e6, "unit": "Mpoint-adds/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/msm_oracle.c (restated src/bigint/msm.ts) on 2^{log2n} points, {dt:.2f} s, "
+                      f"OpenMP over windows; result {'==' if gpu == res else '!='} GPU result",
+            "ms_per_msm": dt * 1e3}
+
+
+if __name__ == "__main__":
+    main()

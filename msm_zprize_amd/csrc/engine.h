@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -477,13 +478,17 @@ class Engine : public IEngine {
   void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb, int r,
                         MsmMeta* d_meta) {
     constexpr int T = Cfg::BATCH_T;
-    dim3 grid((pairs + T - 1) / T), block(T);
+    // pairs per thread: as many as keep >= ~4 workgroups per CU in flight, capped at BATCH_BMAX
+    int B = 1;
+    while (B < BATCH_BMAX && (uint64_t)pairs >= (uint64_t)T * (B * 2) * 1024) B *= 2;
+    if (batch_b_override_ > 0) B = batch_b_override_;
+    dim3 grid((pairs + T * B - 1) / (T * B)), block(T);
     if (safe) {
       hipLaunchKernelGGL((k_batch_add<F, T, true>), grid, block, 0, stream_, slots_.as<uint32_t>(), d_points,
-                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, d_meta);
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
     } else {
       hipLaunchKernelGGL((k_batch_add<F, T, false>), grid, block, 0, stream_, slots_.as<uint32_t>(), d_points,
-                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, d_meta);
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
     }
   }
 
@@ -553,6 +558,7 @@ class Engine : public IEngine {
   hipEvent_t ev_[kMaxEvents] = {};
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
+  int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
   DevBuf digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   MsmMeta* h_meta_ = nullptr;
   uint32_t* h_final_ = nullptr;

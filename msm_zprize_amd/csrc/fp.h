@@ -332,65 +332,168 @@ MSMZ_HD bool fe_is_zero_mod_p(const Fe<F>& a) {
 }
 
 // ---------------------------------------------------------------------------------- inversion
-// Binary extended Euclid on canonical words (the job of the reference's Kaliski almost-inverse,
-// inverse.ts:42-129 + 191-218).  Input and output are *Montgomery* residues: given a*R it
-// returns a^-1 * R.  Returns false (and r = 0) when the input is 0 mod p; the loop is bounded.
+// Modular inversion by a limb-aligned "optimized binary GCD" (Pornin 2020, the same family as the
+// reference's experimental src/inverse/faster-inverse.ts; the job of its Kaliski almost-inverse,
+// inverse.ts:42-129 + 191-218).  Invariants  a = u*y, b = v*y (mod p)  with a = y, b = p, u = 1, v = 0.
+// One outer iteration runs W binary-GCD steps on (low W bits | top ~29 bits) approximations of a and b,
+// collecting them in a 2x2 matrix (f0 g0; f1 g1) with |f|+|g| <= 2^W, then applies the matrix:
+//   (a, b) <- (a f0 + b g0, a f1 + b g1) / 2^W              exact: one limb shift
+//   (u, v) <- (u f0 + v g0, u f1 + v g1) / 2^W  (mod p)     one Montgomery column step
+// so W bits are retired per iteration with ~6 multiply-adds per limb instead of W long shifts/subtracts.
+// A fixed iteration count (bounded by 2*BITS total steps) makes the loop branch-free at wave level.
+// Input and output are *Montgomery* residues: given a*R it returns a^-1 * R.  Returns false (r = 0)
+// when the input is 0 mod p.
 template <class F>
-MSMZ_HD bool fe_inverse(Fe<F>& r, const Fe<F>& a) {
-  constexpr int NW = F::NW;
-  uint32_t u[NW], v[NW], x1[NW], x2[NW];
-  fe_to_canon_words<F>(u, a);
+MSMZ_HD void gcd_apply_exact(Fe<F>& ra, Fe<F>& rb, const Fe<F>& a, const Fe<F>& b, int32_t f0, int32_t g0, int32_t f1,
+                             int32_t g1) {
+  constexpr int N = F::N, W = F::W;
+  constexpr int64_t MASK = ((int64_t)1 << W) - 1;
+  int64_t ca = 0, cb = 0;
 #pragma unroll
-  for (int i = 0; i < NW; i++) {
-    v[i] = F::PW[i];
-    x1[i] = (i == 0) ? 1u : 0u;
-    x2[i] = 0u;
+  for (int j = 0; j < N; j++) {
+    int64_t ta = (int64_t)a.l[j] * f0 + (int64_t)b.l[j] * g0 + ca;
+    int64_t tb = (int64_t)a.l[j] * f1 + (int64_t)b.l[j] * g1 + cb;
+    if (j > 0) {
+      ra.l[j - 1] = (int32_t)(ta & MASK);
+      rb.l[j - 1] = (int32_t)(tb & MASK);
+    }
+    ca = ta >> W;   // j == 0: the low limb is 0 by construction
+    cb = tb >> W;
   }
-  if (words_is_zero<NW>(u)) {
+  ra.l[N - 1] = (int32_t)ca;
+  rb.l[N - 1] = (int32_t)cb;
+}
+
+// r = (u f + v g) / 2^W mod p, result value in (-p, p), limbs normalized with a signed top limb
+template <class F>
+MSMZ_HD void gcd_apply_mod(Fe<F>& r, const Fe<F>& u, const Fe<F>& v, int32_t f, int32_t g) {
+  constexpr int N = F::N, W = F::W;
+  constexpr int64_t MASK = ((int64_t)1 << W) - 1;
+  int64_t t0 = (int64_t)u.l[0] * f + (int64_t)v.l[0] * g;
+  uint32_t q32 = (uint32_t)t0;
+  if (F::PINV != 1u) q32 *= F::PINV;
+  const int32_t q = (int32_t)(q32 & (uint32_t)MASK);   // t0 - q*p_0 = 0 mod 2^W
+  int64_t c = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    int64_t t = (int64_t)u.l[j] * f + (int64_t)v.l[j] * g + (int64_t)q * F::NPL[j] + c;
+    if (j > 0) r.l[j - 1] = (int32_t)(t & MASK);
+    c = t >> W;
+  }
+  r.l[N - 1] = (int32_t)c;
+  // value in (-2p, p): add p when negative
+  const int32_t neg = r.l[N - 1] >> 31;
+#pragma unroll
+  for (int j = 0; j < N; j++) r.l[j] += F::PL[j] & neg;
+}
+
+template <class F>
+MSMZ_HD void fe_neg_normalized(Fe<F>& a) {   // a <- -a, limbs back to normalized form
+  constexpr int N = F::N, W = F::W;
+  constexpr int32_t MASK = (1 << W) - 1;
+  int32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < N - 1; j++) {
+    int32_t t = c - a.l[j];
+    a.l[j] = t & MASK;
+    c = t >> W;
+  }
+  a.l[N - 1] = c - a.l[N - 1];
+}
+
+template <class F>
+MSMZ_HD bool fe_inverse(Fe<F>& r, const Fe<F>& x) {
+  constexpr int N = F::N, W = F::W;
+  constexpr uint64_t LOWMASK = ((uint64_t)1 << W) - 1;
+  Fe<F> a, b, u, v;
+  {
+    // canonical value of x as normalized limbs
+    uint32_t w[F::NW];
+    fe_to_canon_words<F>(w, x);
+    fe_unpack<F>(a, w);
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    b.l[j] = F::PL[j];
+    u.l[j] = (j == 0) ? 1 : 0;
+    v.l[j] = 0;
+  }
+  constexpr int ITERS = (2 * F::BITS + W - 1) / W + 1;
+#pragma unroll 1
+  for (int it = 0; it < ITERS; it++) {
+    // ---- approximations: low W bits + the top bits at a common alignment
+    int h = 0;   // highest limb where a or b is non-zero
+#pragma unroll
+    for (int j = 1; j < N; j++)
+      if ((a.l[j] | b.l[j]) != 0) h = j;
+    uint64_t ah = 0, bh = 0;
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+      if (j == h) {
+        ah = ((uint64_t)(uint32_t)a.l[j] << W) | (uint32_t)a.l[j - 1];
+        bh = ((uint64_t)(uint32_t)b.l[j] << W) | (uint32_t)b.l[j - 1];
+      }
+    }
+    uint64_t xa, xb;
+    if (h <= 1) {
+      // both fit in 2W bits: exact values
+      xa = h == 0 ? (uint64_t)(uint32_t)a.l[0] : ah;
+      xb = h == 0 ? (uint64_t)(uint32_t)b.l[0] : bh;
+    } else {
+      const uint64_t mx = ah | bh;
+      const int len = 64 - __builtin_clzll(mx | 1);      // <= 2W
+      const int sh = len > (W + 1) ? len - (W + 1) : 0;   // keep the top W+1 bits
+      xa = ((ah >> sh) << W) | ((uint64_t)(uint32_t)a.l[0] & LOWMASK);
+      xb = ((bh >> sh) << W) | ((uint64_t)(uint32_t)b.l[0] & LOWMASK);
+    }
+    // ---- W binary steps on the approximations
+    int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+#pragma unroll 1
+    for (int s = 0; s < W; s++) {
+      const bool odd = (xa & 1) != 0;
+      const bool swap = odd && (xa < xb);
+      // conditional swap of (xa, f0, g0) with (xb, f1, g1)
+      const uint64_t ta = swap ? xb : xa, tb = swap ? xa : xb;
+      const int32_t tf0 = swap ? f1 : f0, tg0 = swap ? g1 : g0;
+      const int32_t tf1 = swap ? f0 : f1, tg1 = swap ? g0 : g1;
+      xa = odd ? ta - tb : ta;
+      f0 = odd ? tf0 - tf1 : tf0;
+      g0 = odd ? tg0 - tg1 : tg0;
+      xb = tb;
+      xa >>= 1;
+      f1 = tf1 * 2;
+      g1 = tg1 * 2;
+    }
+    // ---- apply the matrix
+    Fe<F> na, nb, nu, nv;
+    gcd_apply_exact<F>(na, nb, a, b, f0, g0, f1, g1);
+    gcd_apply_mod<F>(nu, u, v, f0, g0);
+    gcd_apply_mod<F>(nv, u, v, f1, g1);
+    if (na.l[N - 1] < 0) {
+      fe_neg_normalized<F>(na);
+      fe_neg<F>(nu, nu);
+    }
+    if (nb.l[N - 1] < 0) {
+      fe_neg_normalized<F>(nb);
+      fe_neg<F>(nv, nv);
+    }
+    a = na;
+    b = nb;
+    u = nu;
+    v = nv;
+  }
+  // gcd ends up in b
+  int32_t rest = b.l[0] ^ 1;
+#pragma unroll
+  for (int j = 1; j < N; j++) rest |= b.l[j];
+  if (rest != 0) {
     fe_zero(r);
     return false;
   }
-  // invariant: x1 * a0 = u, x2 * a0 = v (mod p); u, v > 0; one of them reaches 1
-  auto halve_mod = [](uint32_t* x) {
-    uint32_t carry = 0;
-    if (x[0] & 1u) carry = words_add<NW>(x, x, F::PW);
-#pragma unroll
-    for (int i = 0; i < NW - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
-    x[NW - 1] = (x[NW - 1] >> 1) | (carry << 31);
-  };
-  auto halve = [](uint32_t* x) {
-#pragma unroll
-    for (int i = 0; i < NW - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
-    x[NW - 1] >>= 1;
-  };
-  auto is_one = [](const uint32_t* x) {
-    uint32_t o = x[0] ^ 1u;
-#pragma unroll
-    for (int i = 1; i < NW; i++) o |= x[i];
-    return o == 0;
-  };
-#pragma unroll 1
-  for (int it = 0; it < 4 * F::BITS + 8; it++) {
-    if (is_one(u) || is_one(v)) break;
-    if (!(u[0] & 1u)) {
-      halve(u);
-      halve_mod(x1);
-    } else if (!(v[0] & 1u)) {
-      halve(v);
-      halve_mod(x2);
-    } else if (words_geq<NW>(u, v)) {
-      words_sub<NW>(u, u, v);
-      if (words_sub<NW>(x1, x1, x2)) words_add<NW>(x1, x1, F::PW);
-    } else {
-      words_sub<NW>(v, v, u);
-      if (words_sub<NW>(x2, x2, x1)) words_add<NW>(x2, x2, F::PW);
-    }
-  }
-  const uint32_t* res = is_one(u) ? x1 : x2;
-  Fe<F> t, r3;
-  fe_unpack<F>(t, res);           // (a R)^-1 = a^-1 R^-1
+  Fe<F> r3;
+  fe_carry(v);
   fe_set_const<F>(r3, F::R3);
-  fe_mul<F>(r, t, r3);            // * R^3 / R  ->  a^-1 R
+  fe_mul<F>(r, v, r3);   // (x)^-1 = a^-1 R^-1  ->  * R^3 / R = a^-1 R
   return true;
 }
 

@@ -333,85 +333,145 @@ __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t* curso
 // reference's schedule (msm-batched-affine.ts:232-247).  Sums live in `slots`, one record per sorted
 // position, written in place from round 0 on; round 0 gathers the original points through `refs`.
 //
-// One thread = one pair.  The workgroup inverts all its x-differences together: leaves of a product
-// tree in LDS, up-sweep, ONE field inversion (wave 0, all lanes on the same value -> no divergence),
-// down-sweep.  3 products per element for the inversion + 3 for the affine addition.
+// Batch inversion (Montgomery's trick) on two levels:
+//   * each thread walks B pairs like batchAddUnsafeNew (curve-affine.ts:463-522): forward pass keeps a
+//     running product of the denominators and parks  z_i = numerator_i * prod_{j<i} d_j  in the output
+//     slot's y field; backward pass turns z_i into the slope with the running inverse;
+//   * the T per-thread products of a workgroup are inverted together: product tree in LDS, ONE field
+//     inversion (wave 0, every lane on the same value -> no divergence), down-sweep.
+// 6 field products per addition + (3 T + inversion) per workgroup of T*B additions.
+// Slope/sum formulas use P2 (y3 = m (x2 - x3) - y2, wasm/curve.ts:63-84 addAffinePacked) because y1's
+// slot is where z_i was parked.
 //
 // SAFE handles infinity operands, equal points (doubling, denominator 2y) and opposite points
 // (result infinity) like batchAddNew (curve-affine.ts:376-458); the unsafe variant assumes distinct
-// x like batchAddUnsafeNew (:463-522) and raises meta->error if a zero denominator poisons a batch.
-template <class F, int T, bool SAFE>
-__global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
-                                                 const uint32_t* off, const uint32_t* rscan, uint32_t nb, int r,
-                                                 MsmMeta* meta) {
-  constexpr int N = F::N;
-  constexpr int RW = 2 * F::NW;          // record words
-  // product tree: level d has T >> d nodes, stored limb-major; level offsets 0, T, T + T/2, ...
-  __shared__ int32_t tree[N * 2 * T];
-  const uint32_t total = meta->round_pairs[r];
-  const uint32_t t = blockIdx.x * T + threadIdx.x;
-  const bool active = t < total;
-  const uint32_t m = 1u << r;
+// x like batchAddUnsafeNew and raises meta->error if a zero denominator poisons a batch.
+constexpr int BATCH_BMAX = 16;
+enum { PK_NONE = 0, PK_ADD = 1, PK_DBL = 2, PK_TAKE_A = 3, PK_TAKE_B = 4, PK_INF = 5 };
 
-  Affine<F> p1, p2;
-  Fe<F> leaf;
-  uint32_t posA = 0;
-  bool inf_b = false;
-  int kind = 0;   // 0 = inactive, 1 = add, 2 = double, 3 = result is p1, 4 = result is p2, 5 = result infinity
-  fe_set_const<F>(leaf, F::ONE);
-  if (active) {
-    // bucket of pair t: largest g with rscan[g] <= t
-    uint32_t lo = 0, hi = nb;   // invariant rscan[lo] <= t < rscan[hi]
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (rscan[mid] <= t) lo = mid; else hi = mid;
-    }
-    const uint32_t g = lo;
-    const uint32_t start = off[g], size = off[g + 1] - start;
-    const uint32_t a = (t - rscan[g]) * 2 * m, b = a + m;
-    posA = start + a;
-    const uint32_t posB = start + b;
-    bool infA, infB;
-    if (r == 0) {
-      uint32_t ra = refs[posA], rb = refs[posB];
-      infA = load_affine<F>(p1, points + (size_t)(ra & REF_IDX) * RW, ra >> 31);
-      infB = load_affine<F>(p2, points + (size_t)(rb & REF_IDX) * RW, rb >> 31);
+template <class F>
+struct PairOperands {
+  const uint32_t* recA;
+  const uint32_t* recB;
+  uint32_t negA, negB;
+};
+
+template <class F>
+__device__ __forceinline__ PairOperands<F> pair_operands(uint32_t posA, uint32_t desc, uint32_t m, int r,
+                                                         const uint32_t* slots, const uint32_t* points,
+                                                         const uint32_t* refs) {
+  constexpr int RW = 2 * F::NW;
+  PairOperands<F> o;
+  const uint32_t posB = posA + m;
+  if (r == 0) {
+    uint32_t ra = refs[posA], rb = refs[posB];
+    o.recA = points + (size_t)(ra & REF_IDX) * RW;
+    o.negA = ra >> 31;
+    o.recB = points + (size_t)(rb & REF_IDX) * RW;
+    o.negB = rb >> 31;
+  } else {
+    o.recA = slots + (size_t)posA * RW;
+    o.negA = 0;
+    if (desc & 8u) {   // B was never paired before: still the original point
+      uint32_t rb = refs[posB];
+      o.recB = points + (size_t)(rb & REF_IDX) * RW;
+      o.negB = rb >> 31;
     } else {
-      infA = load_affine<F>(p1, slots + (size_t)posA * RW, 0);
-      if (b + 1 < size) {
-        infB = load_affine<F>(p2, slots + (size_t)posB * RW, 0);
-      } else {   // last element of the bucket was never paired: still the original point
-        uint32_t rb = refs[posB];
-        infB = load_affine<F>(p2, points + (size_t)(rb & REF_IDX) * RW, rb >> 31);
-      }
-    }
-    kind = 1;
-    inf_b = infB;
-    fe_sub(leaf, p2.x, p1.x);
-    if (SAFE) {
-      if (infA) {
-        kind = 4;
-      } else if (infB) {
-        kind = 3;
-      } else if (fe_is_zero(leaf)) {
-        Fe<F> dy;
-        fe_sub(dy, p2.y, p1.y);
-        if (fe_is_zero(dy) && !fe_is_zero(p1.y)) {
-          kind = 2;
-          fe_add(leaf, p1.y, p1.y);
-        } else {
-          kind = 5;
-        }
-      }
-      if (kind >= 3) fe_set_const<F>(leaf, F::ONE);
+      o.recB = slots + (size_t)posB * RW;
+      o.negB = 0;
     }
   }
+  return o;
+}
 
-  // ---- leaves
+template <class F, int T, bool SAFE>
+__global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
+                                                 const uint32_t* off, const uint32_t* rscan, uint32_t nb, int r, int B,
+                                                 MsmMeta* meta) {
+  constexpr int N = F::N;
+  constexpr int NW = F::NW;
+  constexpr int RW = 2 * NW;
+  // product tree: level d has T >> d nodes, stored limb-major; level offsets 0, T, T + T/2, ...
+  __shared__ int32_t tree[N * 2 * T];
+  __shared__ uint32_t s_pos[BATCH_BMAX * T];
+  __shared__ uint32_t s_desc[BATCH_BMAX * T];   // bits 0..2 kind, bit 3 "B is an original point"
+  const uint32_t total = meta->round_pairs[r];
+  const uint32_t m = 1u << r;
+  const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
+
+  Fe<F> prefix;
+  fe_set_const<F>(prefix, F::ONE);
+  // ---------------------------------------------------------------- forward pass
+#pragma unroll 1
+  for (int i = 0; i < B; i++) {
+    const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
+    uint32_t kind = PK_NONE, posA = 0, desc = 0;
+    if (t < total) {
+      uint32_t lo = 0, hi = nb;   // invariant rscan[lo] <= t < rscan[hi]
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (rscan[mid] <= t) lo = mid; else hi = mid;
+      }
+      const uint32_t start = off[lo], size = off[lo + 1] - start;
+      const uint32_t a = (t - rscan[lo]) * 2 * m, b = a + m;
+      posA = start + a;
+      if (r > 0 && !(b + 1 < size)) desc |= 8u;
+      PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
+      Affine<F> p1, p2;
+      bool infA = load_affine<F>(p1, op.recA, op.negA);
+      bool infB = load_affine<F>(p2, op.recB, op.negB);
+      Fe<F> d, num;
+      fe_sub(d, p2.x, p1.x);
+      fe_sub(num, p2.y, p1.y);
+      kind = PK_ADD;
+      if (SAFE) {
+        if (infA) {
+          kind = infB ? PK_INF : PK_TAKE_B;
+        } else if (infB) {
+          kind = PK_TAKE_A;
+        } else if (fe_is_zero(d)) {
+          if (fe_is_zero(num) && !fe_is_zero(p1.y)) {
+            kind = PK_DBL;
+            fe_add(d, p2.y, p2.y);          // 2y
+            Fe<F> xx;
+            fe_sqr(xx, p2.x);
+            fe_add(num, xx, xx);
+            fe_add(num, num, xx);           // 3x^2
+            fe_carry(num);
+          } else {
+            kind = PK_INF;
+          }
+        }
+      }
+      if (kind == PK_ADD || kind == PK_DBL) {
+        Fe<F> z;
+        fe_mul(z, prefix, num);
+        uint32_t w[NW];
+        fe_store_mulout<F>(w, z);
+        uint4* d4 = reinterpret_cast<uint4*>(slots + (size_t)posA * RW + NW);
 #pragma unroll
-  for (int j = 0; j < N; j++) tree[j * 2 * T + threadIdx.x] = leaf.l[j];
+        for (int q = 0; q < NW / 4; q++) d4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        if (r == 0) {
+          // round 0: the slot is fresh; park x1 next to z so the backward pass needs no second gather of A
+          fe_store<F>(w, p1.x);
+          uint4* x4 = reinterpret_cast<uint4*>(slots + (size_t)posA * RW);
+#pragma unroll
+          for (int q = 0; q < NW / 4; q++) x4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        }
+        Fe<F> np;
+        fe_mul(np, prefix, d);
+        prefix = np;
+      }
+      desc |= kind;
+    }
+    s_pos[i * T + threadIdx.x] = posA;
+    s_desc[i * T + threadIdx.x] = desc;
+  }
+
+  // ---------------------------------------------------------------- workgroup-wide inversion of the T products
+#pragma unroll
+  for (int j = 0; j < N; j++) tree[j * 2 * T + threadIdx.x] = prefix.l[j];
   __syncthreads();
-  // ---- up-sweep: node(d+1, i) = node(d, 2i) * node(d, 2i+1)
   int lvl_off = 0;
 #pragma unroll 1
   for (int width = T >> 1; width >= 1; width >>= 1) {
@@ -430,7 +490,6 @@ __global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t
     }
     __syncthreads();
   }
-  // ---- root inversion (lvl_off now addresses the single root node)
   if (threadIdx.x < 64) {
     Fe<F> root, inv;
 #pragma unroll
@@ -443,7 +502,6 @@ __global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t
     }
   }
   __syncthreads();
-  // ---- down-sweep: inv(left) = inv(parent) * right, inv(right) = inv(parent) * left
 #pragma unroll 1
   for (int width = 1; width <= T >> 1; width <<= 1) {
     const int parent_off = lvl_off;
@@ -466,26 +524,61 @@ __global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t
     }
     __syncthreads();
   }
-  if (!active) return;
-  Fe<F> inv;
+  Fe<F> run;   // inverse of the product of this thread's remaining denominators
 #pragma unroll
-  for (int j = 0; j < N; j++) inv.l[j] = tree[j * 2 * T + threadIdx.x];
+  for (int j = 0; j < N; j++) run.l[j] = tree[j * 2 * T + threadIdx.x];
 
-  Affine<F> res;
-  bool res_inf = false;
-  if (!SAFE || kind == 1) {
-    affine_add_with_inv(res, p1, p2, inv);
-  } else if (kind == 2) {
-    affine_double_with_inv(res, p1, inv);
-  } else if (kind == 3) {
-    res = p1;
-  } else if (kind == 4) {
-    res = p2;
-    res_inf = inf_b;   // infinity + infinity stays the all-zero record
-  } else {
-    res_inf = true;
+  // ---------------------------------------------------------------- backward pass
+#pragma unroll 1
+  for (int i = B - 1; i >= 0; i--) {
+    const uint32_t desc = s_desc[i * T + threadIdx.x];
+    const uint32_t kind = desc & 7u;
+    if (kind == PK_NONE) continue;
+    const uint32_t posA = s_pos[i * T + threadIdx.x];
+    uint32_t* out = slots + (size_t)posA * RW;
+    PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
+    if (kind == PK_ADD || kind == PK_DBL) {
+      Affine<F> p2;
+      load_affine<F>(p2, op.recB, op.negB);
+      Fe<F> x1, z, mm, ms, d, t;
+      {
+        uint32_t w[RW];
+        load_words<F>(w, out);            // [x1 | z]  (x1 parked there in round 0, in place otherwise)
+        fe_unpack<F>(x1, w);
+        fe_unpack<F>(z, w + NW);
+      }
+      if (kind == PK_ADD) {
+        fe_sub(d, p2.x, x1);
+      } else {
+        fe_add(d, p2.y, p2.y);
+      }
+      fe_mul(mm, z, run);                 // slope
+      fe_mul(t, run, d);
+      run = t;
+      fe_sqr(ms, mm);
+      Affine<F> res;
+      fe_sub(t, ms, x1);
+      fe_sub(res.x, t, p2.x);             // x3 = m^2 - x1 - x2
+      fe_sub(t, p2.x, res.x);
+      fe_carry(t);
+      fe_mul(ms, mm, t);
+      fe_sub(res.y, ms, p2.y);            // y3 = m (x2 - x3) - y2
+      store_affine<F>(out, res, false);
+    } else if (kind == PK_TAKE_B) {
+      Affine<F> p2;
+      load_affine<F>(p2, op.recB, op.negB);
+      store_affine<F>(out, p2, false);
+    } else if (kind == PK_TAKE_A) {
+      if (r == 0) {
+        Affine<F> p1;
+        load_affine<F>(p1, op.recA, op.negA);
+        store_affine<F>(out, p1, false);
+      }                                   // r > 0: A already sits in the output slot
+    } else {                              // PK_INF
+      Affine<F> dummy;
+      store_affine<F>(out, dummy, true);
+    }
   }
-  store_affine<F>(slots + (size_t)posA * RW, res, res_inf);
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
