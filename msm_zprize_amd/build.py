@@ -1,29 +1,55 @@
-"""Build the HIP shared library (libmsmz.so) in-tree for gfx950.  `python -m msm_zprize_amd.build`."""
+"""Build the HIP shared library (libmsmz.so) in-tree for gfx950.  `python -m msm_zprize_amd.build`.
+
+One translation unit per kernel family, compiled in parallel; objects are cached under csrc/_obj/.
+"""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmsmz.so")
-SOURCES = ["msmz.hip"]
-HEADERS = ["fp.h", "fp_cios.h", "curve.h", "scalar.h", "kernels.h", "gen_kernels.h", "engine.h", "constants_gen.h"]
+SOURCES = ["msmz.hip", "kern_batch.hip", "kern_reduce.hip", "kern_misc.hip", "kern_gen.hip"]
+HEADERS = ["fp.h", "fp_cios.h", "curve.h", "scalar.h", "kernels.h", "gen_kernels.h", "engine.h", "constants_gen.h",
+           "instantiate.h"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value"]
+
+
+def _deps_mtime():
+    deps = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(HERE, "..", "include", "msmz.h")]
+    return max(os.path.getmtime(d) for d in deps)
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "msmz.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _deps_mtime() > t or any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-           "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = _deps_mtime()
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(hdr_t, os.path.getmtime(s)):
+            return o
+        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -117,7 +117,7 @@ class Engine : public IEngine {
   ~Engine() override {
     (void)hipSetDevice(device_);
     for (auto& kv : handles_) (void)hipFree(kv.second.dev);
-    for (DevBuf* b : {&digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+    for (DevBuf* b : {&packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
                       &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
       b->release();
     if (h_meta_) (void)hipHostFree(h_meta_);
@@ -293,7 +293,8 @@ class Engine : public IEngine {
     const int K = (b + 1 + c - 1) / c;                    // msm-batched-affine.ts:96
     const uint32_t L = 1u << (c - 1);
     const uint64_t nb64 = (uint64_t)K * L;
-    if (nb64 + 1 >= (1ull << 31) || (uint64_t)K * M >= (1ull << 31) || K > kMaxWindows) return MSMZ_ERR_ARG;
+    // sorted positions are packed into 28 bits inside k_batch_add
+    if (nb64 + 1 >= (1ull << 31) || (uint64_t)K * M >= (1ull << 28) || K > kMaxWindows) return MSMZ_ERR_ARG;
     const uint32_t nb = (uint32_t)nb64;
     const bool timing = opt.timing != 0;
     int ei = 0;
@@ -313,33 +314,80 @@ class Engine : public IEngine {
 
     MsmMeta* d_meta = meta_.as<MsmMeta>();
     MSMZ_HIP(hipMemsetAsync(d_meta, 0, sizeof(MsmMeta), stream_));
-    MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nb + 1) * 4, stream_));
-    MSMZ_HIP(hipMemsetAsync(cursor_.p, 0, (size_t)nb * 4, stream_));
-
-    mark();  // 0
-    if (glv) {
-      hipLaunchKernelGGL((k_digits<Fr, true>), dim3((n + 255) / 256), dim3(256), 0, stream_, digits_.as<uint32_t>(),
-                         counts_.as<uint32_t>(), d_scalars, n, c, K);
+    // two-level LDS-staged sort when the packed (fine | negate | index) word fits; else per-entry atomics
+    const int fb = (c - 1) < SORT_FB_MAX ? (c - 1) : SORT_FB_MAX;
+    const uint32_t ncb = L >> fb;
+    const uint32_t nbins = (uint32_t)K * ncb;
+    const bool sort2 = !force_atomic_sort_ && M <= (1u << SORT_IDX_BITS) && ncb <= (uint32_t)COARSE_MAX_BINS &&
+                       (size_t)nbins * 4 <= 48 * 1024;
+    int ev_coarse = -1;
+    if (sort2) {
+      if ((st = packed_.ensure((size_t)K * M * 4))) return st;
+      // counts_ = per-bin histogram, cursor_ = per-bin run cursors, bins_ = bin offsets
+      if ((st = bins_.ensure(((size_t)nbins + 1) * 4))) return st;
+      MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nbins + 1) * 4, stream_));
+      MSMZ_HIP(hipMemsetAsync(cursor_.p, 0, (size_t)nbins * 4, stream_));
+      mark();  // 0
+      const uint32_t dgrid = (n + 256 * DIGITS_ITEMS - 1) / (256 * DIGITS_ITEMS);
+      if (glv) {
+        hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), (size_t)nbins * 4, stream_,
+                           digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb);
+      } else {
+        hipLaunchKernelGGL((k_digits<Fr, false>), dim3(dgrid), dim3(256), (size_t)nbins * 4, stream_,
+                           digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb);
+      }
+      mark();  // 1
+      const uint32_t bblocks = (nbins + SCAN_TILE - 1) / SCAN_TILE;
+      hipLaunchKernelGGL(k_scan_partials, dim3(bblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
+                         counts_.as<uint32_t>(), nbins, 0, bblocks);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), bblocks,
+                         &d_meta->n_entries);
+      hipLaunchKernelGGL(k_scan_apply, dim3(bblocks, 1), dim3(SCAN_T), 0, stream_, bins_.as<uint32_t>(),
+                         partials_.as<uint32_t>(), counts_.as<uint32_t>(), nbins, 0, bblocks, (size_t)0,
+                         (uint32_t*)nullptr);
+      mark();  // 2
+      {
+        dim3 grid((M + COARSE_TILE - 1) / COARSE_TILE, K);
+        hipLaunchKernelGGL((k_scatter_coarse<COARSE_MAX_BINS>), grid, dim3(COARSE_T), 0, stream_,
+                           packed_.as<uint32_t>(), cursor_.as<uint32_t>(), bins_.as<uint32_t>(),
+                           digits_.as<uint32_t>(), M, fb, ncb);
+      }
+      ev_coarse = ei;
+      mark();  // coarse done
+      hipLaunchKernelGGL(k_sort_fine, dim3(nbins), dim3(256), 0, stream_, refs_.as<uint32_t>(), off_.as<uint32_t>(),
+                         &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins);
+      mark();  // 3 (index 4 in this path)
     } else {
-      hipLaunchKernelGGL((k_digits<Fr, false>), dim3((n + 255) / 256), dim3(256), 0, stream_, digits_.as<uint32_t>(),
-                         counts_.as<uint32_t>(), d_scalars, n, c, K);
+      MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nb + 1) * 4, stream_));
+      MSMZ_HIP(hipMemsetAsync(cursor_.p, 0, (size_t)nb * 4, stream_));
+      mark();  // 0
+      const uint32_t dgrid = (n + 256 * DIGITS_ITEMS - 1) / (256 * DIGITS_ITEMS);
+      if (glv) {
+        hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), 0, stream_, digits_.as<uint32_t>(),
+                           counts_.as<uint32_t>(), d_scalars, n, c, K, 0);
+      } else {
+        hipLaunchKernelGGL((k_digits<Fr, false>), dim3(dgrid), dim3(256), 0, stream_, digits_.as<uint32_t>(),
+                           counts_.as<uint32_t>(), d_scalars, n, c, K, 0);
+      }
+      mark();  // 1
+      // bucket offsets + max bucket size + total entries
+      hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
+                         counts_.as<uint32_t>(), nb, 0, nblocks);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
+                         &d_meta->n_entries);
+      hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, off_.as<uint32_t>(),
+                         partials_.as<uint32_t>(), counts_.as<uint32_t>(), nb, 0, nblocks, (size_t)0,
+                         &d_meta->max_bucket);
+      mark();  // 2
+      {
+        dim3 grid((M + 256 * 4 - 1) / (256 * 4), K);
+        hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, stream_, refs_.as<uint32_t>(), cursor_.as<uint32_t>(),
+                           off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c);
+      }
+      ev_coarse = ei;
+      mark();  // scatter done
+      mark();  // 3 (index 4)
     }
-    mark();  // 1
-    // bucket offsets + max bucket size + total entries
-    hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
-                       counts_.as<uint32_t>(), nb, 0, nblocks);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
-                       &d_meta->n_entries);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, off_.as<uint32_t>(),
-                       partials_.as<uint32_t>(), counts_.as<uint32_t>(), nb, 0, nblocks, (size_t)0,
-                       &d_meta->max_bucket);
-    mark();  // 2
-    {
-      dim3 grid((M + 256 * 4 - 1) / (256 * 4), K);
-      hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, stream_, refs_.as<uint32_t>(), cursor_.as<uint32_t>(),
-                         off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c);
-    }
-    mark();  // 3
     MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
     const uint32_t max_bucket = h_meta_->max_bucket;
@@ -347,7 +395,7 @@ class Engine : public IEngine {
     const int R = max_bucket <= 1 ? 0 : ceil_log2_u64(max_bucket);   // rounds m = 1, 2, 4, ... < max_bucket
     if (R > 31) return MSMZ_ERR_ARG;
 
-    mark();  // 4
+    mark();  // 5
     if (R > 0) {
       if ((st = rscan_.ensure((size_t)R * ((size_t)nb + 1) * 4))) return st;
       hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, R), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
@@ -360,7 +408,8 @@ class Engine : public IEngine {
       MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
       MSMZ_HIP(hipStreamSynchronize(stream_));
     }
-    mark();  // 5
+    const int ev_plan_end = ei;
+    mark();  // 6
     uint64_t n_pairs = 0;
     const uint32_t* d_points = (const uint32_t*)pts.dev;
     int round_ev0 = ei;
@@ -455,13 +504,13 @@ class Engine : public IEngine {
         };
         log->stage_ms[MSMZ_ST_DIGITS] = el(0, 1);
         log->stage_ms[MSMZ_ST_SCAN] = el(1, 2);
-        log->stage_ms[MSMZ_ST_SCATTER] = el(2, 3);
-        log->scatter_kernel_ms = el(2, 3);
+        log->stage_ms[MSMZ_ST_SCATTER] = el(2, 4);
+        log->scatter_kernel_ms = el(2, ev_coarse);
         log->scatter_launches = 1;
-        log->stage_ms[MSMZ_ST_PLAN] = el(4, 5);
-        log->stage_ms[MSMZ_ST_ACCUMULATE] = el(5, round_ev1);
+        log->stage_ms[MSMZ_ST_PLAN] = el(5, ev_plan_end);
+        log->stage_ms[MSMZ_ST_ACCUMULATE] = el(ev_plan_end, round_ev1);
         log->stage_ms[MSMZ_ST_REDUCE] = el(round_ev1, round_ev1 + 1);
-        int prev = 5, rr = 0;
+        int prev = ev_plan_end, rr = 0;
         for (int r = 0; r < R && rr < 32; r++) {
           if (h_meta_->round_pairs[r] == 0) continue;
           int e = round_ev0 + rr;
@@ -475,20 +524,31 @@ class Engine : public IEngine {
     return MSMZ_OK;
   }
 
-  void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb, int r,
-                        MsmMeta* d_meta) {
-    constexpr int T = Cfg::BATCH_T;
-    // pairs per thread: as many as keep >= ~4 workgroups per CU in flight, capped at BATCH_BMAX
+  template <int T, int OCC, int BMAX>
+  void launch_batch_variant(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb,
+                            int r, MsmMeta* d_meta) {
+    // pairs per thread: as many as keep >= ~4 workgroups per CU in flight, capped at BMAX
     int B = 1;
-    while (B < BATCH_BMAX && (uint64_t)pairs >= (uint64_t)T * (B * 2) * 1024) B *= 2;
-    if (batch_b_override_ > 0) B = batch_b_override_;
+    while (B < BMAX && (uint64_t)pairs >= (uint64_t)T * (B * 2) * 1024) B *= 2;
+    if (batch_b_override_ > 0) B = batch_b_override_ < BMAX ? batch_b_override_ : BMAX;
     dim3 grid((pairs + T * B - 1) / (T * B)), block(T);
     if (safe) {
-      hipLaunchKernelGGL((k_batch_add<F, T, true>), grid, block, 0, stream_, slots_.as<uint32_t>(), d_points,
-                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
+      hipLaunchKernelGGL((k_batch_add<F, T, true, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
+                         d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
     } else {
-      hipLaunchKernelGGL((k_batch_add<F, T, false>), grid, block, 0, stream_, slots_.as<uint32_t>(), d_points,
-                         refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
+      hipLaunchKernelGGL((k_batch_add<F, T, false, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
+                         d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
+    }
+  }
+
+  void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb, int r,
+                        MsmMeta* d_meta) {
+    switch (batch_variant_) {
+      case 1: launch_batch_variant<256, 3, 16>(pairs, safe, d_points, rs, nb, r, d_meta); break;
+      case 2: launch_batch_variant<256, 4, 16>(pairs, safe, d_points, rs, nb, r, d_meta); break;
+      case 3: launch_batch_variant<512, 2, 8>(pairs, safe, d_points, rs, nb, r, d_meta); break;
+      case 4: launch_batch_variant<512, 4, 8>(pairs, safe, d_points, rs, nb, r, d_meta); break;
+      default: launch_batch_variant<256, 2, 16>(pairs, safe, d_points, rs, nb, r, d_meta); break;
     }
   }
 
@@ -558,8 +618,10 @@ class Engine : public IEngine {
   hipEvent_t ev_[kMaxEvents] = {};
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
+  bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
+  int batch_variant_ = getenv("MSMZ_BATCH_VARIANT") ? atoi(getenv("MSMZ_BATCH_VARIANT")) : 0;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
-  DevBuf digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   MsmMeta* h_meta_ = nullptr;
   uint32_t* h_final_ = nullptr;
 };

@@ -158,52 +158,83 @@ __global__ void __launch_bounds__(256) k_points_from_mont(uint32_t* out, const u
 
 // ------------------------------------------------------------------------------------------------ digits
 // digits[k*M + i] for i in [0, M): M = N (no GLV) or 2N (GLV: entry N+i is the endomorphism half).
+// `shift` = 0: counts[] is the per-bucket histogram (one global atomic per entry; fallback path).
+// shift = FB > 0 (two-level sort): counts[] is the per-coarse-bin histogram, bin = k * (L >> FB) + ((l-1) >> FB),
+// accumulated in LDS (dynamic shared memory: K * (L >> FB) words) and flushed with one atomic per bin.
+constexpr int DIGITS_ITEMS = 8;
+
 template <class Fr, bool GLV>
 __global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* counts, const uint32_t* scalars,
-                                                uint32_t n, int c, int K) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                                uint32_t n, int c, int K, int shift) {
+  extern __shared__ uint32_t s_hist[];
   const uint32_t L = 1u << (c - 1);
   const uint32_t M = GLV ? 2 * n : n;
-  uint32_t s[8];
-  {
-    const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-    uint4 a = p4[0], b = p4[1];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
-    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  const uint32_t bins_per_window = L >> shift;
+  const uint32_t nbins = (uint32_t)K * bins_per_window;
+  if (shift) {
+    for (uint32_t b = threadIdx.x; b < nbins; b += 256) s_hist[b] = 0;
+    __syncthreads();
   }
-  if (GLV) {
-    uint32_t h[2][4], neg[2];
-    glv_decompose<Fr>(h[0], h[1], neg[0], neg[1], s);
+  auto tally = [&](uint32_t k, uint32_t l) {
+    if (l == 0) return;
+    const uint32_t bin = k * bins_per_window + ((l - 1) >> shift);
+    if (shift) {
+      atomicAdd(&s_hist[bin], 1u);
+    } else {
+      atomicAdd(&counts[bin], 1u);
+    }
+  };
+#pragma unroll 1
+  for (int item = 0; item < DIGITS_ITEMS; item++) {
+    const uint32_t i = (blockIdx.x * DIGITS_ITEMS + item) * 256 + threadIdx.x;
+    if (i >= n) continue;
+    uint32_t s[8];
+    {
+      const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+      uint4 a = p4[0], b = p4[1];
+      s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+      s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    }
+    if (GLV) {
+      uint32_t h[2][4], neg[2];
+      glv_decompose<Fr>(h[0], h[1], neg[0], neg[1], s);
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
+      for (int half = 0; half < 2; half++) {
+        uint32_t carry = 0;
+        for (int k = 0; k < K; k++) {
+          uint32_t l = extract_bits<4>(h[half], k * c, c) + carry;
+          if (l > L) {
+            l = 2 * L - l;
+            carry = 1;
+          } else {
+            carry = 0;
+          }
+          // the half scalar's own sign flips every digit's sign
+          uint32_t ng = (carry ^ neg[half]) & (l != 0 ? 1u : 0u);
+          digits[(size_t)k * M + (size_t)half * n + i] = l | (ng << 31);
+          tally(k, l);
+        }
+      }
+    } else {
       uint32_t carry = 0;
       for (int k = 0; k < K; k++) {
-        uint32_t l = extract_bits<4>(h[half], k * c, c) + carry;
+        uint32_t l = extract_bits<8>(s, k * c, c) + carry;
         if (l > L) {
           l = 2 * L - l;
           carry = 1;
         } else {
           carry = 0;
         }
-        // the half scalar's own sign flips every digit's sign
-        uint32_t ng = (carry ^ neg[half]) & (l != 0 ? 1u : 0u);
-        digits[(size_t)k * M + (size_t)half * n + i] = l | (ng << 31);
-        if (l != 0) atomicAdd(&counts[(size_t)k * L + (l - 1)], 1u);
+        digits[(size_t)k * M + i] = l | (carry << 31);
+        tally(k, l);
       }
     }
-  } else {
-    uint32_t carry = 0;
-    for (int k = 0; k < K; k++) {
-      uint32_t l = extract_bits<8>(s, k * c, c) + carry;
-      if (l > L) {
-        l = 2 * L - l;
-        carry = 1;
-      } else {
-        carry = 0;
-      }
-      digits[(size_t)k * M + i] = l | (carry << 31);
-      if (l != 0) atomicAdd(&counts[(size_t)k * L + (l - 1)], 1u);
+  }
+  if (shift) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
+      const uint32_t v = s_hist[b];
+      if (v) atomicAdd(&counts[b], v);
     }
   }
 }
@@ -248,7 +279,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   return base + x - v;
 }
 
-__global__ void __launch_bounds__(SCAN_T) k_scan_partials(uint32_t* partials, const uint32_t* in, uint32_t n, int mode,
+static __global__ void __launch_bounds__(SCAN_T) k_scan_partials(uint32_t* partials, const uint32_t* in, uint32_t n, int mode,
                                                           uint32_t nblocks) {
   __shared__ uint32_t lds[SCAN_T / 64];
   const int r = blockIdx.y;
@@ -262,7 +293,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_partials(uint32_t* partials, co
 }
 
 // one block per round: exclusive scan of the per-tile partials (in place); writes the grand total
-__global__ void __launch_bounds__(SCAN_T) k_scan_top(uint32_t* partials, uint32_t nblocks, uint32_t* totals) {
+static __global__ void __launch_bounds__(SCAN_T) k_scan_top(uint32_t* partials, uint32_t nblocks, uint32_t* totals) {
   __shared__ uint32_t lds[SCAN_T / 64];
   const int r = blockIdx.x;
   uint32_t* p = partials + (size_t)r * nblocks;
@@ -278,7 +309,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_top(uint32_t* partials, uint32_
   if (threadIdx.x == 0) totals[r] = running;
 }
 
-__global__ void __launch_bounds__(SCAN_T) k_scan_apply(uint32_t* out, const uint32_t* partials, const uint32_t* in,
+static __global__ void __launch_bounds__(SCAN_T) k_scan_apply(uint32_t* out, const uint32_t* partials, const uint32_t* in,
                                                        uint32_t n, int mode, uint32_t nblocks, size_t out_stride,
                                                        uint32_t* max_out) {
   __shared__ uint32_t lds[SCAN_T / 64];
@@ -307,7 +338,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_apply(uint32_t* out, const uint
 // refs[off[g] + (arrival order within bucket g)] = i | negate<<31  for every non-zero digit.
 // (This is the HBM-bound "bucket scatter": algorithmic bytes = 4 B digit read + 4 B reference write
 // per entry)
-__global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t* cursor, const uint32_t* off,
+static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t* cursor, const uint32_t* off,
                                                  const uint32_t* digits, uint32_t M, int c) {
   constexpr int ITEMS = 4;
   const uint32_t L = 1u << (c - 1);
@@ -324,6 +355,125 @@ __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t* curso
     uint32_t g = k * L + (l - 1);
     uint32_t pos = off[g] + atomicAdd(&cursor[g], 1u);
     refs[pos] = i | (d & REF_NEG);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ two-level sort
+// Replacement for {global-atomic histogram, k_scatter} when M <= 2^23: a most-significant-digit radix
+// partition of the (bucket, reference) pairs in two LDS-staged passes, so that no pass issues one
+// global atomic per entry and every global store instruction writes contiguous runs.
+//
+//   digit l in [1, L]  ->  i = l - 1 = (coarse << FB) | fine,   FB = min(8, c-1) fine bits
+//   coarse bin  id  = k * NCB + coarse      (NCB = 2^(c-1-FB) bins per window; consecutive buckets)
+//
+//   k_digits (SORT2 mode)  per-workgroup LDS histogram of coarse bins, flushed with one atomic per bin
+//   scan                   bin offsets (tiny)
+//   k_scatter_coarse       THE HBM-bound bucket scatter: reads each digit (4 B), stages a tile in LDS sorted
+//                          by coarse bin, writes (fine | negate | index) words (4 B) in contiguous runs
+//   k_sort_fine            one workgroup per coarse bin: LDS histogram of its <= 256 buckets -> bucket
+//                          offsets `off`, then places every reference at its final sorted position
+constexpr int SORT_FB_MAX = 8;
+constexpr int SORT_IDX_BITS = 23;
+constexpr uint32_t SORT_IDX_MASK = (1u << SORT_IDX_BITS) - 1;
+constexpr int COARSE_T = 256;
+constexpr int COARSE_ITEMS = 32;
+constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // 8192 entries per workgroup
+constexpr int COARSE_MAX_BINS = 512;                  // bins per window the LDS staging supports
+
+template <int NBINS_MAX>
+static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* packed_out, uint32_t* bin_cursor,
+                                                                    const uint32_t* bin_base, const uint32_t* digits,
+                                                                    uint32_t M, int fb, uint32_t ncb) {
+  __shared__ uint32_t s_cnt[NBINS_MAX];     // entries of this tile per bin, then exclusive scan
+  __shared__ uint32_t s_gbase[NBINS_MAX];   // global base of this tile's run in each bin
+  __shared__ uint32_t s_stage[COARSE_TILE];
+  __shared__ uint16_t s_bin[COARSE_TILE];
+  __shared__ uint32_t s_wave[COARSE_T / 64];
+  const uint32_t k = blockIdx.y;
+  const uint32_t* dk = digits + (size_t)k * M;
+  const uint32_t tile0 = blockIdx.x * COARSE_TILE;
+  for (uint32_t b = threadIdx.x; b < ncb; b += COARSE_T) s_cnt[b] = 0;
+  __syncthreads();
+  uint32_t val[COARSE_ITEMS], rank[COARSE_ITEMS];
+  uint16_t bin[COARSE_ITEMS];
+#pragma unroll
+  for (int j = 0; j < COARSE_ITEMS; j++) {
+    const uint32_t i = tile0 + j * COARSE_T + threadIdx.x;
+    bin[j] = 0xffff;
+    if (i < M) {
+      const uint32_t d = dk[i];
+      const uint32_t l = d & REF_IDX;
+      if (l != 0) {
+        const uint32_t idx = l - 1;
+        bin[j] = (uint16_t)(idx >> fb);
+        val[j] = ((idx & ((1u << fb) - 1u)) << (SORT_IDX_BITS + 1)) | ((d >> 31) << SORT_IDX_BITS) | i;
+        rank[j] = atomicAdd(&s_cnt[bin[j]], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // reserve the runs in global memory, and scan the counts for the staging order
+  uint32_t my_cnt[NBINS_MAX / COARSE_T], my_sum = 0;
+#pragma unroll
+  for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
+    const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
+    my_cnt[q] = b < ncb ? s_cnt[b] : 0;
+    my_sum += my_cnt[q];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(my_sum, &total, s_wave);
+#pragma unroll
+  for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
+    const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
+    if (b < ncb) {
+      s_cnt[b] = ex;
+      const uint32_t gb = k * ncb + b;
+      s_gbase[b] = my_cnt[q] ? bin_base[gb] + atomicAdd(&bin_cursor[gb], my_cnt[q]) - ex : 0u;
+      ex += my_cnt[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < COARSE_ITEMS; j++) {
+    if (bin[j] != 0xffff) {
+      const uint32_t p = s_cnt[bin[j]] + rank[j];
+      s_stage[p] = val[j];
+      s_bin[p] = bin[j];
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < total; p += COARSE_T) packed_out[s_gbase[s_bin[p]] + p] = s_stage[p];
+}
+
+// One workgroup per coarse bin.  Phase A: histogram of the bin's buckets in LDS -> off[] for those buckets
+// (+ running maximum bucket size); phase B: every entry goes to its final position.
+static __global__ void __launch_bounds__(256) k_sort_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
+                                                          const uint32_t* packed, const uint32_t* bin_base, int fb,
+                                                          uint32_t n_bins) {
+  __shared__ uint32_t s_cnt[1 << SORT_FB_MAX];
+  __shared__ uint32_t s_cur[1 << SORT_FB_MAX];
+  __shared__ uint32_t s_wave[4];
+  const uint32_t bin = blockIdx.x;
+  const uint32_t nfine = 1u << fb;
+  const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
+  if (threadIdx.x < nfine) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t p = begin + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[packed[p] >> (SORT_IDX_BITS + 1)], 1u);
+  __syncthreads();
+  const uint32_t c = threadIdx.x < nfine ? s_cnt[threadIdx.x] : 0;
+  uint32_t total;
+  const uint32_t ex = block_exclusive_scan(c, &total, s_wave);
+  if (threadIdx.x < nfine) {
+    s_cur[threadIdx.x] = begin + ex;
+    off[(size_t)bin * nfine + threadIdx.x] = begin + ex;
+    if (c > 1) atomicMax(max_bucket, c);
+  }
+  if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
+  __syncthreads();
+  for (uint32_t p = begin + threadIdx.x; p < end; p += 256) {
+    const uint32_t v = packed[p];
+    const uint32_t pos = atomicAdd(&s_cur[v >> (SORT_IDX_BITS + 1)], 1u);
+    refs[pos] = (v & SORT_IDX_MASK) | (((v >> SORT_IDX_BITS) & 1u) << 31);
   }
 }
 
@@ -384,17 +534,17 @@ __device__ __forceinline__ PairOperands<F> pair_operands(uint32_t posA, uint32_t
   return o;
 }
 
-template <class F, int T, bool SAFE>
-__global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
+template <class F, int T, bool SAFE, int OCC, int BMAX>
+__global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
                                                  const uint32_t* off, const uint32_t* rscan, uint32_t nb, int r, int B,
                                                  MsmMeta* meta) {
   constexpr int N = F::N;
   constexpr int NW = F::NW;
   constexpr int RW = 2 * NW;
-  // product tree: level d has T >> d nodes, stored limb-major; level offsets 0, T, T + T/2, ...
-  __shared__ int32_t tree[N * 2 * T];
-  __shared__ uint32_t s_pos[BATCH_BMAX * T];
-  __shared__ uint32_t s_desc[BATCH_BMAX * T];   // bits 0..2 kind, bit 3 "B is an original point"
+  // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
+  // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
+  __shared__ int32_t tree[N * T];
+  __shared__ uint32_t s_desc[BMAX * T];   // posA | kind << 28 | "B is an original point" << 31
   const uint32_t total = meta->round_pairs[r];
   const uint32_t m = 1u << r;
   const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
@@ -464,77 +614,92 @@ __global__ void __launch_bounds__(T) k_batch_add(uint32_t* slots, const uint32_t
       }
       desc |= kind;
     }
-    s_pos[i * T + threadIdx.x] = posA;
-    s_desc[i * T + threadIdx.x] = desc;
+    s_desc[i * T + threadIdx.x] = posA | (desc << 28);
   }
 
   // ---------------------------------------------------------------- workgroup-wide inversion of the T products
+  {
+    Fe<F> partner, node;
 #pragma unroll
-  for (int j = 0; j < N; j++) tree[j * 2 * T + threadIdx.x] = prefix.l[j];
+    for (int j = 0; j < N; j++) partner.l[j] = __shfl_xor(prefix.l[j], 1, 64);
+    fe_mul(node, prefix, partner);
+    if ((threadIdx.x & 1) == 0) {
+#pragma unroll
+      for (int j = 0; j < N; j++) tree[j * T + (threadIdx.x >> 1)] = node.l[j];
+    }
+  }
   __syncthreads();
-  int lvl_off = 0;
+  int lvl_off = 0;   // offset of the level being consumed (level 1 first)
 #pragma unroll 1
-  for (int width = T >> 1; width >= 1; width >>= 1) {
+  for (int width = T >> 2; width >= 1; width >>= 1) {
     const int child_off = lvl_off;
     lvl_off += width * 2;
     if ((int)threadIdx.x < width) {
       Fe<F> x, y, z;
 #pragma unroll
       for (int j = 0; j < N; j++) {
-        x.l[j] = tree[j * 2 * T + child_off + 2 * threadIdx.x];
-        y.l[j] = tree[j * 2 * T + child_off + 2 * threadIdx.x + 1];
+        x.l[j] = tree[j * T + child_off + 2 * threadIdx.x];
+        y.l[j] = tree[j * T + child_off + 2 * threadIdx.x + 1];
       }
       fe_mul(z, x, y);
 #pragma unroll
-      for (int j = 0; j < N; j++) tree[j * 2 * T + lvl_off + threadIdx.x] = z.l[j];
+      for (int j = 0; j < N; j++) tree[j * T + lvl_off + threadIdx.x] = z.l[j];
     }
     __syncthreads();
   }
   if (threadIdx.x < 64) {
     Fe<F> root, inv;
 #pragma unroll
-    for (int j = 0; j < N; j++) root.l[j] = tree[j * 2 * T + lvl_off];
+    for (int j = 0; j < N; j++) root.l[j] = tree[j * T + lvl_off];
     bool ok = fe_inverse(inv, root);
     if (threadIdx.x == 0) {
       if (!ok) atomicOr(&meta->error, 1u);
 #pragma unroll
-      for (int j = 0; j < N; j++) tree[j * 2 * T + lvl_off] = inv.l[j];
+      for (int j = 0; j < N; j++) tree[j * T + lvl_off] = inv.l[j];
     }
   }
   __syncthreads();
 #pragma unroll 1
-  for (int width = 1; width <= T >> 1; width <<= 1) {
+  for (int width = 1; width <= T >> 2; width <<= 1) {
     const int parent_off = lvl_off;
     lvl_off -= width * 2;
     if ((int)threadIdx.x < width) {
       Fe<F> pi, x, y, xi, yi;
 #pragma unroll
       for (int j = 0; j < N; j++) {
-        pi.l[j] = tree[j * 2 * T + parent_off + threadIdx.x];
-        x.l[j] = tree[j * 2 * T + lvl_off + 2 * threadIdx.x];
-        y.l[j] = tree[j * 2 * T + lvl_off + 2 * threadIdx.x + 1];
+        pi.l[j] = tree[j * T + parent_off + threadIdx.x];
+        x.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x];
+        y.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x + 1];
       }
       fe_mul(xi, pi, y);
       fe_mul(yi, pi, x);
 #pragma unroll
       for (int j = 0; j < N; j++) {
-        tree[j * 2 * T + lvl_off + 2 * threadIdx.x] = xi.l[j];
-        tree[j * 2 * T + lvl_off + 2 * threadIdx.x + 1] = yi.l[j];
+        tree[j * T + lvl_off + 2 * threadIdx.x] = xi.l[j];
+        tree[j * T + lvl_off + 2 * threadIdx.x + 1] = yi.l[j];
       }
     }
     __syncthreads();
   }
-  Fe<F> run;   // inverse of the product of this thread's remaining denominators
+  Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
+  {
+    Fe<F> partner, ninv;
 #pragma unroll
-  for (int j = 0; j < N; j++) run.l[j] = tree[j * 2 * T + threadIdx.x];
+    for (int j = 0; j < N; j++) {
+      partner.l[j] = __shfl_xor(prefix.l[j], 1, 64);
+      ninv.l[j] = tree[j * T + (threadIdx.x >> 1)];
+    }
+    fe_mul(run, ninv, partner);
+  }
 
   // ---------------------------------------------------------------- backward pass
 #pragma unroll 1
   for (int i = B - 1; i >= 0; i--) {
-    const uint32_t desc = s_desc[i * T + threadIdx.x];
+    const uint32_t packed = s_desc[i * T + threadIdx.x];
+    const uint32_t desc = packed >> 28;
     const uint32_t kind = desc & 7u;
     if (kind == PK_NONE) continue;
-    const uint32_t posA = s_pos[i * T + threadIdx.x];
+    const uint32_t posA = packed & 0x0fffffffu;
     uint32_t* out = slots + (size_t)posA * RW;
     PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
     if (kind == PK_ADD || kind == PK_DBL) {

@@ -1,4 +1,10 @@
 // C ABI of the MSM engine (include/msmz.h): curve dispatch + argument checking.
+#include "instantiate.h"
+namespace msmz {
+#define X(F, Fr) MSMZ_INST_BATCH(F, Fr, MSMZ_EXTERN) MSMZ_INST_REDUCE(F, Fr, MSMZ_EXTERN) MSMZ_INST_MISC(F, Fr, MSMZ_EXTERN) MSMZ_INST_GEN(F, Fr, MSMZ_EXTERN)
+MSMZ_WEIERSTRASS_FIELDS(X)
+#undef X
+}  // namespace msmz
 #include "engine.h"
 
 namespace msmz {
@@ -14,7 +20,7 @@ struct CfgBls377 {
   using F = Bls377Fp;
   using Fr = Bls377Fr;
   static constexpr bool HAS_ENDO = true;
-  static constexpr int BATCH_T = 256;
+  static constexpr int BATCH_T = MSMZ_BATCH_T;
   static int run_msm(Engine<CfgBls377>& e, const Handle& p, const uint32_t* s, uint64_t n, const msmz_opts& o,
                      uint8_t* out, int* oi, msmz_log* log) {
     return run_weierstrass(e, p, s, n, o, out, oi, log);

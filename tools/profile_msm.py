@@ -22,4 +22,5 @@ for rep in range(a.reps):
 print(f"n=2^{a.log2n} c={st.c} K={st.K} rounds={st.rounds} entries={st.n_entries} pairs={st.n_pairs} maxb={st.max_bucket}")
 names = ["digits", "scan", "scatter", "plan", "accumulate", "reduce", "final", "total"]
 print("  ".join(f"{nm}={st.stage_ms[i]:.3f}" for i, nm in enumerate(names)))
+print(f"scatter coarse kernel = {st.scatter_kernel_ms:.4f} ms -> {st.K * n * (2 if a.glv else 1) * 8 / st.scatter_kernel_ms / 1e6:.1f} GB/s algorithmic")
 print("rounds ms:", " ".join(f"{st.batch_add_ms[r]:.3f}" for r in range(st.rounds)))
