@@ -12,6 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmsmz.so")
 SOURCES = ["msmz.hip", "kern_batch.hip", "kern_reduce.hip", "kern_misc.hip", "kern_gen.hip"]
+# (source, curve id) translation units; curve 3 (twisted Edwards) has no batched-affine kernels
+UNITS = [("msmz.hip", None)] + [(f, c) for c in (0, 1, 2, 3) for f in SOURCES[1:] if not (f == "kern_batch.hip" and c == 3)]
 HEADERS = ["fp.h", "fp_cios.h", "curve.h", "scalar.h", "kernels.h", "gen_kernels.h", "engine.h", "constants_gen.h",
            "instantiate.h"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value"]
@@ -36,19 +38,20 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hdr_t = _deps_mtime()
 
-    def compile_one(src):
+    def compile_one(unit):
+        src, curve = unit
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, src.replace(".hip", "" if curve is None else f"_c{curve}") + ".o")
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(hdr_t, os.path.getmtime(s)):
             return o
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + ([] if curve is None else [f"-DMSMZ_CURVE={curve}"]) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         return o
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, UNITS))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -101,6 +101,8 @@ class Engine : public IEngine {
   static constexpr int RW = 2 * NW;      // affine record words
   static constexpr int XW = 4 * NW;      // XYZZ / extended record words
   static constexpr int FE_BYTES = NW * 4;
+  static constexpr bool TE = Cfg::TE;
+  static constexpr int PW_WORDS = TE ? 4 * NW : 2 * NW;   // device point record words
 
  public:
   explicit Engine(int device) : device_(device) {}
@@ -148,9 +150,14 @@ class Engine : public IEngine {
     }
     const bool endo = Cfg::HAS_ENDO;
     void* dev = nullptr;
-    MSMZ_HIP(hipMalloc(&dev, (size_t)n * RW * 4 * (endo ? 2 : 1)));
-    hipLaunchKernelGGL((k_points_to_mont<F>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)dev,
-                       stage_.as<uint32_t>(), d_inf, (uint32_t)n, endo ? 1 : 0);
+    MSMZ_HIP(hipMalloc(&dev, (size_t)n * PW_WORDS * 4 * (endo ? 2 : 1)));
+    if constexpr (TE) {
+      hipLaunchKernelGGL((k_te_points_to_niels<F>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)dev,
+                         stage_.as<uint32_t>(), (uint32_t)n);
+    } else {
+      hipLaunchKernelGGL((k_points_to_mont<F>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)dev,
+                         stage_.as<uint32_t>(), d_inf, (uint32_t)n, endo ? 1 : 0);
+    }
     MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipStreamSynchronize(stream_));
     *h = next_handle_++;
@@ -179,9 +186,14 @@ class Engine : public IEngine {
     if (st) return st;
     const bool endo = Cfg::HAS_ENDO;
     void* dev = nullptr;
-    MSMZ_HIP(hipMalloc(&dev, (size_t)n * RW * 4 * (endo ? 2 : 1)));
-    hipLaunchKernelGGL((k_gen_points<F>), dim3((n + 127) / 128), dim3(128), 0, stream_, (uint32_t*)dev,
-                       gen_table_.as<uint32_t>(), (uint32_t)n, seed, endo ? 1 : 0);
+    MSMZ_HIP(hipMalloc(&dev, (size_t)n * PW_WORDS * 4 * (endo ? 2 : 1)));
+    if constexpr (TE) {
+      hipLaunchKernelGGL((k_te_gen_points<F>), dim3((n + 127) / 128), dim3(128), 0, stream_, (uint32_t*)dev,
+                         gen_table_.as<uint32_t>(), (uint32_t)n, seed);
+    } else {
+      hipLaunchKernelGGL((k_gen_points<F>), dim3((n + 127) / 128), dim3(128), 0, stream_, (uint32_t*)dev,
+                         gen_table_.as<uint32_t>(), (uint32_t)n, seed, endo ? 1 : 0);
+    }
     MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipStreamSynchronize(stream_));
     *h = next_handle_++;
@@ -211,14 +223,19 @@ class Engine : public IEngine {
     MSMZ_HIP(hipSetDevice(device_));
     int st = stage_.ensure(count * RW * 4);
     if (st) return st;
-    hipLaunchKernelGGL((k_points_from_mont<F>), dim3((count + 255) / 256), dim3(256), 0, stream_,
-                       stage_.as<uint32_t>(), (const uint32_t*)it->second.dev + first * RW, (uint32_t)count);
+    if constexpr (TE) {
+      hipLaunchKernelGGL((k_te_points_from_niels<F>), dim3((count + 255) / 256), dim3(256), 0, stream_,
+                         stage_.as<uint32_t>(), (const uint32_t*)it->second.dev + first * PW_WORDS, (uint32_t)count);
+    } else {
+      hipLaunchKernelGGL((k_points_from_mont<F>), dim3((count + 255) / 256), dim3(256), 0, stream_,
+                         stage_.as<uint32_t>(), (const uint32_t*)it->second.dev + first * PW_WORDS, (uint32_t)count);
+    }
     MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipMemcpyAsync(xy, stage_.p, count * RW * 4, hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
     if (inf) {
       for (uint64_t i = 0; i < count; i++) {
-        bool z = true;
+        bool z = !TE;   // twisted Edwards has no point at infinity: the identity is the affine point (0, 1)
         for (int j = 0; j < RW * 4; j++) z = z && xy[i * RW * 4 + j] == 0;
         inf[i] = z ? 1 : 0;
       }
@@ -277,66 +294,82 @@ class Engine : public IEngine {
     return st;
   }
 
-  // ------------------------------------------------------------------------------------------ Weierstrass, affine buckets
-  int msm_weierstrass_affine(const Handle& pts, const uint32_t* d_scalars, uint64_t n64, const msmz_opts& opt,
-                             uint8_t* out, int* out_inf, msmz_log* log) {
-    const uint32_t n = (uint32_t)n64;
-    const bool glv = opt.glv != 0;
-    if (glv && (!Fr::HAS_GLV || !pts.has_endo)) return MSMZ_ERR_UNSUPPORTED;
-    // GLV addresses the endomorphism images at index handle.n + i, so the MSM must cover the whole set
-    if (glv && n != pts.n) return MSMZ_ERR_UNSUPPORTED;
-    const uint32_t M = glv ? 2 * n : n;
-    const int b = glv ? Fr::GLV_BITS - 1 : Fr::BITS;      // scalar bit length
-    int c = opt.c > 0 ? opt.c : default_window(M);
-    if (c < 2) c = 2;
-    if (c > 24) c = 24;
-    const int K = (b + 1 + c - 1) / c;                    // msm-batched-affine.ts:96
-    const uint32_t L = 1u << (c - 1);
-    const uint64_t nb64 = (uint64_t)K * L;
-    // sorted positions are packed into 28 bits inside k_batch_add
-    if (nb64 + 1 >= (1ull << 31) || (uint64_t)K * M >= (1ull << 28) || K > kMaxWindows) return MSMZ_ERR_ARG;
-    const uint32_t nb = (uint32_t)nb64;
-    const bool timing = opt.timing != 0;
-    int ei = 0;
-    auto mark = [&]() {
-      if (timing && ei < kMaxEvents) (void)hipEventRecord(ev_[ei++], stream_);
-    };
+  // ------------------------------------------------------------------------------------------ shared phases
+  struct Plan {
+    uint32_t n, M, L, nb, nblocks;
+    int c, K, b;
+    bool glv, timing;
+    uint32_t max_bucket = 0, n_entries = 0;
+    int ei = 0;                 // next event slot
+    int ev_coarse = -1, ev_sort_end = -1;
+  };
 
+  void mark(Plan& pl) {
+    if (pl.timing && pl.ei < kMaxEvents) (void)hipEventRecord(ev_[pl.ei], stream_);
+    pl.ei++;
+  }
+  float elapsed(int a, int b2) {
+    float ms = 0;
+    if (a >= 0 && b2 >= 0 && a < kMaxEvents && b2 < kMaxEvents) (void)hipEventElapsedTime(&ms, ev_[a], ev_[b2]);
+    return ms;
+  }
+
+  int make_plan(Plan& pl, uint64_t n64, bool glv, const msmz_opts& opt, uint32_t pts_n) {
+    pl.n = (uint32_t)n64;
+    pl.glv = glv;
+    pl.M = glv ? 2 * pl.n : pl.n;
+    pl.b = glv ? Fr::GLV_BITS - 1 : Fr::BITS;                 // scalar bit length
+    pl.c = opt.c > 0 ? opt.c : default_window(pl.M);
+    if (pl.c < 2) pl.c = 2;
+    if (pl.c > 24) pl.c = 24;
+    pl.K = (pl.b + 1 + pl.c - 1) / pl.c;                      // msm-batched-affine.ts:96
+    pl.L = 1u << (pl.c - 1);
+    const uint64_t nb64 = (uint64_t)pl.K * pl.L;
+    if (nb64 + 1 >= (1ull << 31) || (uint64_t)pl.K * pl.M >= (1ull << 32) || pl.K > kMaxWindows) return MSMZ_ERR_ARG;
+    pl.nb = (uint32_t)nb64;
+    pl.nblocks = (pl.nb + SCAN_TILE - 1) / SCAN_TILE;
+    pl.timing = opt.timing != 0;
+    (void)pts_n;
+    return MSMZ_OK;
+  }
+
+  // digits -> sorted references `refs_` + bucket offsets `off_`; events 0..4; reads back max bucket / entries
+  int sort_phase(Plan& pl, const uint32_t* d_scalars) {
+    const uint32_t n = pl.n, M = pl.M, L = pl.L, nb = pl.nb, nblocks = pl.nblocks;
+    const int c = pl.c, K = pl.K;
     int st;
     if ((st = digits_.ensure((size_t)K * M * 4))) return st;
     if ((st = refs_.ensure((size_t)K * M * 4))) return st;
     if ((st = counts_.ensure(((size_t)nb + 1) * 4))) return st;
     if ((st = off_.ensure(((size_t)nb + 1) * 4))) return st;
     if ((st = cursor_.ensure((size_t)nb * 4))) return st;
-    const uint32_t nblocks = (nb + SCAN_TILE - 1) / SCAN_TILE;
     if ((st = partials_.ensure((size_t)32 * nblocks * 4))) return st;
-    if ((st = slots_.ensure((size_t)K * M * RW * 4))) return st;
-
     MsmMeta* d_meta = meta_.as<MsmMeta>();
     MSMZ_HIP(hipMemsetAsync(d_meta, 0, sizeof(MsmMeta), stream_));
     // two-level LDS-staged sort when the packed (fine | negate | index) word fits; else per-entry atomics
-    const int fb = (c - 1) < SORT_FB_MAX ? (c - 1) : SORT_FB_MAX;
+    const int idx_bits = M <= (1u << 23) ? 23 : 24;
+    const int fb_max = 31 - idx_bits;
+    const int fb = (c - 1) < fb_max ? (c - 1) : fb_max;
     const uint32_t ncb = L >> fb;
     const uint32_t nbins = (uint32_t)K * ncb;
-    const bool sort2 = !force_atomic_sort_ && M <= (1u << SORT_IDX_BITS) && ncb <= (uint32_t)COARSE_MAX_BINS &&
+    const bool sort2 = !force_atomic_sort_ && M <= (1u << 24) && ncb <= (uint32_t)COARSE_MAX_BINS &&
                        (size_t)nbins * 4 <= 48 * 1024;
-    int ev_coarse = -1;
+    const uint32_t dgrid = (n + 256 * DIGITS_ITEMS - 1) / (256 * DIGITS_ITEMS);
     if (sort2) {
       if ((st = packed_.ensure((size_t)K * M * 4))) return st;
-      // counts_ = per-bin histogram, cursor_ = per-bin run cursors, bins_ = bin offsets
       if ((st = bins_.ensure(((size_t)nbins + 1) * 4))) return st;
       MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nbins + 1) * 4, stream_));
       MSMZ_HIP(hipMemsetAsync(cursor_.p, 0, (size_t)nbins * 4, stream_));
-      mark();  // 0
-      const uint32_t dgrid = (n + 256 * DIGITS_ITEMS - 1) / (256 * DIGITS_ITEMS);
-      if (glv) {
-        hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), (size_t)nbins * 4, stream_,
-                           digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb);
+      mark(pl);  // 0
+      if (pl.glv) {
+        if constexpr (Fr::HAS_GLV)
+          hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), (size_t)nbins * 4, stream_,
+                             digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb);
       } else {
         hipLaunchKernelGGL((k_digits<Fr, false>), dim3(dgrid), dim3(256), (size_t)nbins * 4, stream_,
                            digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb);
       }
-      mark();  // 1
+      mark(pl);  // 1
       const uint32_t bblocks = (nbins + SCAN_TILE - 1) / SCAN_TILE;
       hipLaunchKernelGGL(k_scan_partials, dim3(bblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
                          counts_.as<uint32_t>(), nbins, 0, bblocks);
@@ -345,32 +378,30 @@ class Engine : public IEngine {
       hipLaunchKernelGGL(k_scan_apply, dim3(bblocks, 1), dim3(SCAN_T), 0, stream_, bins_.as<uint32_t>(),
                          partials_.as<uint32_t>(), counts_.as<uint32_t>(), nbins, 0, bblocks, (size_t)0,
                          (uint32_t*)nullptr);
-      mark();  // 2
+      mark(pl);  // 2
       {
         dim3 grid((M + COARSE_TILE - 1) / COARSE_TILE, K);
         hipLaunchKernelGGL((k_scatter_coarse<COARSE_MAX_BINS>), grid, dim3(COARSE_T), 0, stream_,
                            packed_.as<uint32_t>(), cursor_.as<uint32_t>(), bins_.as<uint32_t>(),
-                           digits_.as<uint32_t>(), M, fb, ncb);
+                           digits_.as<uint32_t>(), M, fb, ncb, idx_bits);
       }
-      ev_coarse = ei;
-      mark();  // coarse done
+      pl.ev_coarse = pl.ei;
+      mark(pl);  // 3
       hipLaunchKernelGGL(k_sort_fine, dim3(nbins), dim3(256), 0, stream_, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                         &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins);
-      mark();  // 3 (index 4 in this path)
+                         &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins, idx_bits);
     } else {
       MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nb + 1) * 4, stream_));
       MSMZ_HIP(hipMemsetAsync(cursor_.p, 0, (size_t)nb * 4, stream_));
-      mark();  // 0
-      const uint32_t dgrid = (n + 256 * DIGITS_ITEMS - 1) / (256 * DIGITS_ITEMS);
-      if (glv) {
-        hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), 0, stream_, digits_.as<uint32_t>(),
-                           counts_.as<uint32_t>(), d_scalars, n, c, K, 0);
+      mark(pl);  // 0
+      if (pl.glv) {
+        if constexpr (Fr::HAS_GLV)
+          hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), 0, stream_, digits_.as<uint32_t>(),
+                             counts_.as<uint32_t>(), d_scalars, n, c, K, 0);
       } else {
         hipLaunchKernelGGL((k_digits<Fr, false>), dim3(dgrid), dim3(256), 0, stream_, digits_.as<uint32_t>(),
                            counts_.as<uint32_t>(), d_scalars, n, c, K, 0);
       }
-      mark();  // 1
-      // bucket offsets + max bucket size + total entries
+      mark(pl);  // 1
       hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
                          counts_.as<uint32_t>(), nb, 0, nblocks);
       hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
@@ -378,98 +409,74 @@ class Engine : public IEngine {
       hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, off_.as<uint32_t>(),
                          partials_.as<uint32_t>(), counts_.as<uint32_t>(), nb, 0, nblocks, (size_t)0,
                          &d_meta->max_bucket);
-      mark();  // 2
+      mark(pl);  // 2
       {
         dim3 grid((M + 256 * 4 - 1) / (256 * 4), K);
         hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, stream_, refs_.as<uint32_t>(), cursor_.as<uint32_t>(),
                            off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c);
       }
-      ev_coarse = ei;
-      mark();  // scatter done
-      mark();  // 3 (index 4)
+      pl.ev_coarse = pl.ei;
+      mark(pl);  // 3
     }
+    pl.ev_sort_end = pl.ei;
+    mark(pl);  // 4
+    MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
-    const uint32_t max_bucket = h_meta_->max_bucket;
-    const uint32_t n_entries = h_meta_->n_entries;
-    const int R = max_bucket <= 1 ? 0 : ceil_log2_u64(max_bucket);   // rounds m = 1, 2, 4, ... < max_bucket
-    if (R > 31) return MSMZ_ERR_ARG;
+    pl.max_bucket = h_meta_->max_bucket;
+    pl.n_entries = h_meta_->n_entries;
+    return MSMZ_OK;
+  }
 
-    mark();  // 5
-    if (R > 0) {
-      if ((st = rscan_.ensure((size_t)R * ((size_t)nb + 1) * 4))) return st;
-      hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, R), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
-                         off_.as<uint32_t>(), nb, 1, nblocks);
-      hipLaunchKernelGGL(k_scan_top, dim3(R), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
-                         d_meta->round_pairs);
-      hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, R), dim3(SCAN_T), 0, stream_, rscan_.as<uint32_t>(),
-                         partials_.as<uint32_t>(), off_.as<uint32_t>(), nb, 1, nblocks, (size_t)nb + 1,
-                         (uint32_t*)nullptr);
-      MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
-      MSMZ_HIP(hipStreamSynchronize(stream_));
-    }
-    const int ev_plan_end = ei;
-    mark();  // 6
-    uint64_t n_pairs = 0;
-    const uint32_t* d_points = (const uint32_t*)pts.dev;
-    int round_ev0 = ei;
-    for (int r = 0; r < R; r++) {
-      const uint32_t pairs = h_meta_->round_pairs[r];
-      n_pairs += pairs;
-      if (pairs == 0) continue;
-      const uint32_t* rs = rscan_.as<uint32_t>() + (size_t)r * ((size_t)nb + 1);
-      launch_batch_add(pairs, opt.safe != 0, d_points, rs, nb, r, d_meta);
-      mark();
-    }
-    int round_ev1 = ei;
-    mark();  // accumulate end
-
-    // ---- bucket reduction: level 1 from affine bucket sums, then XYZZ levels down to one entry per window
-    uint32_t S1 = 2;
-    while ((uint64_t)K * (L / (S1 * 2)) >= 131072 && S1 * 2 <= L && S1 < 16) S1 *= 2;
-    if (S1 > L) S1 = L;
-    uint32_t groups = (L + S1 - 1) / S1;
-    if ((st = red_[0].ensure((size_t)K * groups * XW * 4))) return st;
-    if ((st = red_[1].ensure((size_t)K * groups * XW * 4))) return st;
-    {
-      uint32_t total = K * groups;
-      hipLaunchKernelGGL((k_reduce_first<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
-                         red_[0].as<uint32_t>(), red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points,
-                         refs_.as<uint32_t>(), off_.as<uint32_t>(), L, S1, groups, total);
-    }
-    int shift = ceil_log2_u64(S1);
-    int cur = 0;   // rows in red_[cur*2], C in red_[cur*2+1]
-    uint32_t n_in = groups;
+  // reduce levels on accumulator records: rows in red_[cur*2], C in red_[cur*2+1]; ends with one entry per window
+  template <class P>
+  int reduce_levels(const Plan& pl, int& cur, uint32_t n_in, int shift) {
+    constexpr int AW = P::ACC_WORDS;
+    int st;
     while (n_in > 1) {
       uint32_t S = n_in <= 8 ? (1u << ceil_log2_u64(n_in)) : 4;
       uint32_t g2 = (n_in + S - 1) / S;
       int nxt = cur ^ 1;
-      if ((st = red_[nxt * 2].ensure((size_t)K * g2 * XW * 4))) return st;
-      if ((st = red_[nxt * 2 + 1].ensure((size_t)K * g2 * XW * 4))) return st;
-      uint32_t total = K * g2;
-      hipLaunchKernelGGL((k_reduce_next<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
+      if ((st = red_[nxt * 2].ensure((size_t)pl.K * g2 * AW * 4))) return st;
+      if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.K * g2 * AW * 4))) return st;
+      uint32_t total = pl.K * g2;
+      hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_,
                          red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(), red_[cur * 2].as<uint32_t>(),
-                         red_[cur * 2 + 1].as<uint32_t>(), n_in, S, g2, total, shift);
+                         red_[cur * 2 + 1].as<uint32_t>(), (const uint32_t*)nullptr, n_in, S, g2, total, shift);
       shift += ceil_log2_u64(S);
       n_in = g2;
       cur = nxt;
     }
-    mark();  // reduce end
-    MSMZ_HIP(hipGetLastError());
-    MSMZ_HIP(hipMemcpyAsync(h_final_, red_[cur * 2].p, (size_t)K * XW * 4, hipMemcpyDeviceToHost, stream_));
-    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * XW, red_[cur * 2 + 1].p, (size_t)K * XW * 4,
-                            hipMemcpyDeviceToHost, stream_));
-    MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
-    MSMZ_HIP(hipStreamSynchronize(stream_));
-    auto t_host0 = std::chrono::steady_clock::now();
-    if (h_meta_->error & 1u) return MSMZ_ERR_DEGENERATE;
+    return MSMZ_OK;
+  }
 
-    // ---- final sum on the host (msm-batched-affine.ts:300-322): W_k = C_k + row_k, Horner over windows
+  uint32_t first_group_size(const Plan& pl) const {
+    uint32_t S1 = 2;
+    while ((uint64_t)pl.K * (pl.L / (S1 * 2)) >= 131072 && S1 * 2 <= pl.L && S1 < 16) S1 *= 2;
+    if (S1 > pl.L) S1 = pl.L;
+    return S1;
+  }
+
+  // copy the K (row, C) pairs to the host
+  template <class P>
+  int fetch_window_sums(const Plan& pl, int cur) {
+    constexpr int AW = P::ACC_WORDS;
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipMemcpyAsync(h_final_, red_[cur * 2].p, (size_t)pl.K * AW * 4, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, red_[cur * 2 + 1].p, (size_t)pl.K * AW * 4,
+                            hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipMemcpyAsync(h_meta_, meta_.p, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    return MSMZ_OK;
+  }
+
+  // final sum on the host (msm-batched-affine.ts:300-322): W_k = C_k + row_k, Horner over windows
+  void finalize_weierstrass(const Plan& pl, uint8_t* out, int* out_inf) {
     Xyzz<F> acc;
     xyzz_set_inf(acc);
-    for (int k = K - 1; k >= 0; k--) {
-      if (k != K - 1)
-        for (int j = 0; j < c; j++) {
+    for (int k = pl.K - 1; k >= 0; k--) {
+      if (k != pl.K - 1)
+        for (int j = 0; j < pl.c; j++) {
           Xyzz<F> t;
           xyzz_dbl(t, acc);
           acc = t;
@@ -485,70 +492,241 @@ class Engine : public IEngine {
     bool inf = xyzz_to_affine_canon<F>(res, acc);
     memcpy(out, res, RW * 4);
     *out_inf = inf ? 1 : 0;
+  }
 
-    if (log) {
-      log->c = c;
-      log->K = K;
-      log->rounds = R;
-      log->glv = glv ? 1 : 0;
-      log->n_entries = n_entries;
-      log->n_pairs = n_pairs;
-      log->max_bucket = max_bucket;
-      log->stage_ms[MSMZ_ST_FINAL] =
-          std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-      if (timing) {
-        auto el = [&](int a, int b2) {
-          float ms = 0;
-          (void)hipEventElapsedTime(&ms, ev_[a], ev_[b2]);
-          return ms;
-        };
-        log->stage_ms[MSMZ_ST_DIGITS] = el(0, 1);
-        log->stage_ms[MSMZ_ST_SCAN] = el(1, 2);
-        log->stage_ms[MSMZ_ST_SCATTER] = el(2, 4);
-        log->scatter_kernel_ms = el(2, ev_coarse);
-        log->scatter_launches = 1;
-        log->stage_ms[MSMZ_ST_PLAN] = el(5, ev_plan_end);
-        log->stage_ms[MSMZ_ST_ACCUMULATE] = el(ev_plan_end, round_ev1);
-        log->stage_ms[MSMZ_ST_REDUCE] = el(round_ev1, round_ev1 + 1);
-        int prev = ev_plan_end, rr = 0;
-        for (int r = 0; r < R && rr < 32; r++) {
-          if (h_meta_->round_pairs[r] == 0) continue;
-          int e = round_ev0 + rr;
-          if (e >= kMaxEvents) break;
-          log->batch_add_ms[r] = el(prev, e);
-          prev = e;
-          rr++;
-        }
-      }
+  void fill_log(msmz_log* log, const Plan& pl, int R, uint64_t n_pairs, int ev_plan0, int ev_plan1, int ev_acc_end,
+                int ev_red_end, int round_ev0, float host_ms) {
+    if (!log) return;
+    log->c = pl.c;
+    log->K = pl.K;
+    log->rounds = R;
+    log->glv = pl.glv ? 1 : 0;
+    log->n_entries = pl.n_entries;
+    log->n_pairs = n_pairs;
+    log->max_bucket = pl.max_bucket;
+    log->stage_ms[MSMZ_ST_FINAL] = host_ms;
+    if (!pl.timing) return;
+    log->stage_ms[MSMZ_ST_DIGITS] = elapsed(0, 1);
+    log->stage_ms[MSMZ_ST_SCAN] = elapsed(1, 2);
+    log->stage_ms[MSMZ_ST_SCATTER] = elapsed(2, pl.ev_sort_end);
+    log->scatter_kernel_ms = elapsed(2, pl.ev_coarse);
+    log->scatter_launches = 1;
+    log->stage_ms[MSMZ_ST_PLAN] = elapsed(ev_plan0, ev_plan1);
+    log->stage_ms[MSMZ_ST_ACCUMULATE] = elapsed(ev_plan1, ev_acc_end);
+    log->stage_ms[MSMZ_ST_REDUCE] = elapsed(ev_acc_end, ev_red_end);
+    int prev = ev_plan1, rr = 0;
+    for (int r = 0; r < R && r < 32; r++) {
+      if (h_round_pairs_[r] == 0) continue;
+      int e = round_ev0 + rr;
+      if (e >= kMaxEvents) break;
+      log->batch_add_ms[r] = elapsed(prev, e);
+      prev = e;
+      rr++;
     }
+  }
+
+  // ------------------------------------------------------------------------------------------ Weierstrass, affine buckets
+  int msm_weierstrass_affine(const Handle& pts, const uint32_t* d_scalars, uint64_t n64, const msmz_opts& opt,
+                             uint8_t* out, int* out_inf, msmz_log* log) {
+    const bool glv = opt.glv != 0;
+    if (glv && (!Fr::HAS_GLV || !pts.has_endo)) return MSMZ_ERR_UNSUPPORTED;
+    // GLV addresses the endomorphism images at index handle.n + i, so the MSM must cover the whole set
+    if (glv && n64 != pts.n) return MSMZ_ERR_UNSUPPORTED;
+    Plan pl;
+    int st = make_plan(pl, n64, glv, opt, (uint32_t)pts.n);
+    if (st) return st;
+    // sorted positions are packed into 28 bits inside k_batch_add
+    if ((uint64_t)pl.K * pl.M >= (1ull << 28)) return MSMZ_ERR_ARG;
+    if ((st = slots_.ensure((size_t)pl.K * pl.M * RW * 4))) return st;
+    if ((st = sort_phase(pl, d_scalars))) return st;
+    const uint32_t nb = pl.nb, nblocks = pl.nblocks;
+    MsmMeta* d_meta = meta_.as<MsmMeta>();
+    const int R = pl.max_bucket <= 1 ? 0 : ceil_log2_u64(pl.max_bucket);   // rounds m = 1, 2, 4, ... < max_bucket
+    if (R > 31) return MSMZ_ERR_ARG;
+
+    const int ev_plan0 = pl.ei;
+    mark(pl);
+    memset(h_round_pairs_, 0, sizeof(h_round_pairs_));
+    if (R > 0) {
+      if ((st = rscan_.ensure((size_t)R * ((size_t)nb + 1) * 4))) return st;
+      hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, R), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
+                         off_.as<uint32_t>(), nb, 1, nblocks);
+      hipLaunchKernelGGL(k_scan_top, dim3(R), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
+                         d_meta->round_pairs);
+      hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, R), dim3(SCAN_T), 0, stream_, rscan_.as<uint32_t>(),
+                         partials_.as<uint32_t>(), off_.as<uint32_t>(), nb, 1, nblocks, (size_t)nb + 1,
+                         (uint32_t*)nullptr);
+      MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
+      MSMZ_HIP(hipStreamSynchronize(stream_));
+      memcpy(h_round_pairs_, h_meta_->round_pairs, sizeof(h_round_pairs_));
+    }
+    const int ev_plan1 = pl.ei;
+    mark(pl);
+    uint64_t n_pairs = 0;
+    const uint32_t* d_points = (const uint32_t*)pts.dev;
+    const int round_ev0 = pl.ei;
+    for (int r = 0; r < R; r++) {
+      const uint32_t pairs = h_round_pairs_[r];
+      n_pairs += pairs;
+      if (pairs == 0) continue;
+      const uint32_t* rs = rscan_.as<uint32_t>() + (size_t)r * ((size_t)nb + 1);
+      launch_batch_add(pairs, opt.safe != 0, d_points, rs, nb, r, d_meta);
+      mark(pl);
+    }
+    const int ev_acc_end = pl.ei;
+    mark(pl);
+
+    // ---- bucket reduction: level 1 from affine bucket sums, then XYZZ levels down to one entry per window
+    using P = WeierPolicy<F>;
+    const uint32_t S1 = first_group_size(pl);
+    const uint32_t groups = (pl.L + S1 - 1) / S1;
+    if ((st = red_[0].ensure((size_t)pl.K * groups * XW * 4))) return st;
+    if ((st = red_[1].ensure((size_t)pl.K * groups * XW * 4))) return st;
+    {
+      uint32_t total = pl.K * groups;
+      hipLaunchKernelGGL((k_reduce_first<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
+                         red_[0].as<uint32_t>(), red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points,
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), pl.L, S1, groups, total);
+    }
+    int cur = 0;
+    if ((st = reduce_levels<P>(pl, cur, groups, ceil_log2_u64(S1)))) return st;
+    const int ev_red_end = pl.ei;
+    mark(pl);
+    if ((st = fetch_window_sums<P>(pl, cur))) return st;
+    auto t_host0 = std::chrono::steady_clock::now();
+    if (h_meta_->error & 1u) return MSMZ_ERR_DEGENERATE;
+    finalize_weierstrass(pl, out, out_inf);
+    float host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    fill_log(log, pl, R, n_pairs, ev_plan0, ev_plan1, ev_acc_end, ev_red_end, round_ev0, host_ms);
     return MSMZ_OK;
   }
 
-  template <int T, int OCC, int BMAX>
-  void launch_batch_variant(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb,
-                            int r, MsmMeta* d_meta) {
+  // ------------------------------------------------------------------------------------------ msmBasic: projective / extended buckets
+  // (msm-basic.ts:45-176; Weierstrass "projective fallback" parallel.ts:69-87 and the twisted-Edwards MSM)
+  template <class P>
+  int msm_basic(const Handle& pts, const uint32_t* d_scalars, uint64_t n64, const msmz_opts& opt, Plan& pl) {
+    int st = make_plan(pl, n64, false, opt, (uint32_t)pts.n);
+    if (st) return st;
+    if ((st = sort_phase(pl, d_scalars))) return st;
+    constexpr int AW = P::ACC_WORDS;
+    const uint32_t nb = pl.nb, nblocks = pl.nblocks;
+    MsmMeta* d_meta = meta_.as<MsmMeta>();
+    const int ev_plan0 = pl.ei;
+    mark(pl);
+    // chunk offsets: cscan[g] = sum_{g' < g} ceil(size/64)
+    if ((st = rscan_.ensure(((size_t)nb + 1) * 4))) return st;
+    hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
+                       off_.as<uint32_t>(), nb, 2, nblocks);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
+                       d_meta->round_pairs);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, rscan_.as<uint32_t>(),
+                       partials_.as<uint32_t>(), off_.as<uint32_t>(), nb, 2, nblocks, (size_t)0, (uint32_t*)nullptr);
+    MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    const uint32_t n_chunks = h_meta_->round_pairs[0];
+    const int ev_plan1 = pl.ei;
+    mark(pl);
+    if ((st = slots_.ensure((size_t)(n_chunks + 1) * AW * 4))) return st;
+    if (n_chunks > 0) {
+      hipLaunchKernelGGL((k_bucket_accumulate<P>), dim3((n_chunks + 127) / 128), dim3(128), 0, stream_,
+                         slots_.as<uint32_t>(), (const uint32_t*)pts.dev, refs_.as<uint32_t>(), off_.as<uint32_t>(),
+                         rscan_.as<uint32_t>(), nb, n_chunks);
+    }
+    const int ev_acc_end = pl.ei;
+    mark(pl);
+    const uint32_t S1 = first_group_size(pl);
+    const uint32_t groups = (pl.L + S1 - 1) / S1;
+    if ((st = red_[0].ensure((size_t)pl.K * groups * AW * 4))) return st;
+    if ((st = red_[1].ensure((size_t)pl.K * groups * AW * 4))) return st;
+    {
+      uint32_t total = pl.K * groups;
+      hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_, red_[0].as<uint32_t>(),
+                         red_[1].as<uint32_t>(), slots_.as<uint32_t>(), (const uint32_t*)nullptr,
+                         rscan_.as<uint32_t>(), pl.L, S1, groups, total, 0);
+    }
+    int cur = 0;
+    if ((st = reduce_levels<P>(pl, cur, groups, ceil_log2_u64(S1)))) return st;
+    const int ev_red_end = pl.ei;
+    mark(pl);
+    if ((st = fetch_window_sums<P>(pl, cur))) return st;
+    basic_ev_[0] = ev_plan0;
+    basic_ev_[1] = ev_plan1;
+    basic_ev_[2] = ev_acc_end;
+    basic_ev_[3] = ev_red_end;
+    return MSMZ_OK;
+  }
+
+  int msm_weierstrass_projective(const Handle& pts, const uint32_t* d_scalars, uint64_t n64, const msmz_opts& opt,
+                                 uint8_t* out, int* out_inf, msmz_log* log) {
+    if (opt.glv) return MSMZ_ERR_UNSUPPORTED;   // msmProjective never uses the endomorphism (parallel.ts:69-87)
+    Plan pl;
+    int st = msm_basic<WeierPolicy<F>>(pts, d_scalars, n64, opt, pl);
+    if (st) return st;
+    auto t_host0 = std::chrono::steady_clock::now();
+    finalize_weierstrass(pl, out, out_inf);
+    float host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    memset(h_round_pairs_, 0, sizeof(h_round_pairs_));
+    fill_log(log, pl, 0, pl.n_entries, basic_ev_[0], basic_ev_[1], basic_ev_[2], basic_ev_[3], 0, host_ms);
+    return MSMZ_OK;
+  }
+
+  // twisted Edwards MSM (parallel.ts:179-289 -> msm-basic.ts): extended buckets, no GLV
+  int msm_twisted_edwards(const Handle& pts, const uint32_t* d_scalars, uint64_t n64, const msmz_opts& opt,
+                          uint8_t* out, int* out_inf, msmz_log* log) {
+    if (opt.glv) return MSMZ_ERR_UNSUPPORTED;   // the reference's TE path has no endomorphism (msm-basic.ts:4)
+    Plan pl;
+    int st = msm_basic<TePolicy<F>>(pts, d_scalars, n64, opt, pl);
+    if (st) return st;
+    auto t_host0 = std::chrono::steady_clock::now();
+    TeExt<F> acc;
+    te_set_zero(acc);
+    for (int k = pl.K - 1; k >= 0; k--) {
+      if (k != pl.K - 1)
+        for (int j = 0; j < pl.c; j++) {
+          TeExt<F> t;
+          te_add(t, acc, acc);
+          acc = t;
+        }
+      TeExt<F> row, cc, w, t;
+      host_load_te(row, h_final_ + (size_t)k * XW);
+      host_load_te(cc, h_final_ + (size_t)(kMaxWindows + k) * XW);
+      te_add(w, row, cc);
+      te_add(t, acc, w);
+      acc = t;
+    }
+    uint32_t res[RW];
+    te_to_affine_canon<F>(res, acc);
+    memcpy(out, res, RW * 4);
+    *out_inf = 0;
+    float host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    memset(h_round_pairs_, 0, sizeof(h_round_pairs_));
+    fill_log(log, pl, 0, pl.n_entries, basic_ev_[0], basic_ev_[1], basic_ev_[2], basic_ev_[3], 0, host_ms);
+    return MSMZ_OK;
+  }
+
+  static void host_load_te(TeExt<F>& p, const uint32_t* w) {
+    fe_unpack<F>(p.X, w);
+    fe_unpack<F>(p.Y, w + NW);
+    fe_unpack<F>(p.Z, w + 2 * NW);
+    fe_unpack<F>(p.T, w + 3 * NW);
+  }
+
+  void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb, int r,
+                        MsmMeta* d_meta) {
+    constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
     // pairs per thread: as many as keep >= ~4 workgroups per CU in flight, capped at BMAX
     int B = 1;
     while (B < BMAX && (uint64_t)pairs >= (uint64_t)T * (B * 2) * 1024) B *= 2;
     if (batch_b_override_ > 0) B = batch_b_override_ < BMAX ? batch_b_override_ : BMAX;
     dim3 grid((pairs + T * B - 1) / (T * B)), block(T);
-    if (safe) {
-      hipLaunchKernelGGL((k_batch_add<F, T, true, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
-                         d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
-    } else {
-      hipLaunchKernelGGL((k_batch_add<F, T, false, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
-                         d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
-    }
-  }
-
-  void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint32_t* rs, uint32_t nb, int r,
-                        MsmMeta* d_meta) {
-    switch (batch_variant_) {
-      case 1: launch_batch_variant<256, 3, 16>(pairs, safe, d_points, rs, nb, r, d_meta); break;
-      case 2: launch_batch_variant<256, 4, 16>(pairs, safe, d_points, rs, nb, r, d_meta); break;
-      case 3: launch_batch_variant<512, 2, 8>(pairs, safe, d_points, rs, nb, r, d_meta); break;
-      case 4: launch_batch_variant<512, 4, 8>(pairs, safe, d_points, rs, nb, r, d_meta); break;
-      default: launch_batch_variant<256, 2, 16>(pairs, safe, d_points, rs, nb, r, d_meta); break;
+    if constexpr (!TE) {
+      if (safe) {
+        hipLaunchKernelGGL((k_batch_add<F, T, true, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
+                           d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
+      } else {
+        hipLaunchKernelGGL((k_batch_add<F, T, false, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
+                           d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(), rs, nb, r, B, d_meta);
+      }
     }
   }
 
@@ -574,28 +752,53 @@ class Engine : public IEngine {
     if (st) return st;
     // bases 2^(13 k) * G computed on the host, multiples on the device
     uint32_t bases[GEN_WINDOWS * RW];
-    Xyzz<F> g;
     Affine<F> ga;
     fe_set_const<F>(ga.x, F::GX);
     fe_set_const<F>(ga.y, F::GY);
-    xyzz_from_affine(g, ga);
-    for (int k = 0; k < GEN_WINDOWS; k++) {
-      // store affine (Montgomery, lazy) of the current base
-      Affine<F> a;
-      host_xyzz_to_affine_mont(a, g);
-      fe_store<F>(bases + k * RW, a.x);
-      fe_store<F>(bases + k * RW + NW, a.y);
-      for (int j = 0; j < GEN_BITS; j++) {
-        Xyzz<F> t;
-        xyzz_dbl(t, g);
-        g = t;
+    if constexpr (TE) {
+      TeExt<F> g;
+      g.X = ga.x;
+      g.Y = ga.y;
+      fe_set_const<F>(g.Z, F::ONE);
+      fe_mul(g.T, ga.x, ga.y);
+      for (int k = 0; k < GEN_WINDOWS; k++) {
+        Fe<F> zi, x, y;
+        fe_inverse(zi, g.Z);
+        fe_mul(x, g.X, zi);
+        fe_mul(y, g.Y, zi);
+        fe_store<F>(bases + k * RW, x);
+        fe_store<F>(bases + k * RW + NW, y);
+        for (int j = 0; j < GEN_BITS; j++) {
+          TeExt<F> t;
+          te_add(t, g, g);
+          g = t;
+        }
+      }
+    } else {
+      Xyzz<F> g;
+      xyzz_from_affine(g, ga);
+      for (int k = 0; k < GEN_WINDOWS; k++) {
+        Affine<F> a;
+        host_xyzz_to_affine_mont(a, g);
+        fe_store<F>(bases + k * RW, a.x);
+        fe_store<F>(bases + k * RW + NW, a.y);
+        for (int j = 0; j < GEN_BITS; j++) {
+          Xyzz<F> t;
+          xyzz_dbl(t, g);
+          g = t;
+        }
       }
     }
     st = stage_.ensure(sizeof(bases));
     if (st) return st;
     MSMZ_HIP(hipMemcpyAsync(stage_.p, bases, sizeof(bases), hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL((k_gen_table<F>), dim3((GEN_WINDOWS * GEN_TABLE + 127) / 128), dim3(128), 0, stream_,
-                       gen_table_.as<uint32_t>(), stage_.as<uint32_t>());
+    if constexpr (TE) {
+      hipLaunchKernelGGL((k_te_gen_table<F>), dim3((GEN_WINDOWS * GEN_TABLE + 127) / 128), dim3(128), 0, stream_,
+                         gen_table_.as<uint32_t>(), stage_.as<uint32_t>());
+    } else {
+      hipLaunchKernelGGL((k_gen_table<F>), dim3((GEN_WINDOWS * GEN_TABLE + 127) / 128), dim3(128), 0, stream_,
+                         gen_table_.as<uint32_t>(), stage_.as<uint32_t>());
+    }
     MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipStreamSynchronize(stream_));
     return MSMZ_OK;
@@ -619,9 +822,10 @@ class Engine : public IEngine {
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
-  int batch_variant_ = getenv("MSMZ_BATCH_VARIANT") ? atoi(getenv("MSMZ_BATCH_VARIANT")) : 0;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
   DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  uint32_t h_round_pairs_[32] = {};
+  int basic_ev_[4] = {};
   MsmMeta* h_meta_ = nullptr;
   uint32_t* h_final_ = nullptr;
 };

@@ -119,4 +119,117 @@ __global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* out, uint32_t n, 
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// ------------------------------------------------------------------------------------------------ twisted Edwards
+// Device records of twisted-Edwards input points are "Niels" form + x:  [y-x | y+x | 2d*x*y | x]
+// (4*NW words).  The reference stores extended (X, Y, Z=1, T) instead (parallel.ts:209-232).
+template <class F>
+__device__ __forceinline__ void te_store_niels(uint32_t* rec, const Fe<F>& x, const Fe<F>& y) {
+  Fe<F> ym, yp, t, k, kt;
+  fe_sub(ym, y, x);
+  fe_add(yp, y, x);
+  fe_mul(t, x, y);
+  fe_set_const<F>(k, F::K2D);
+  fe_mul(kt, t, k);
+  uint32_t w[2 * F::NW];
+  fe_store<F>(w, ym);
+  fe_store<F>(w + F::NW, yp);
+  store_words<F>(rec, w);
+  fe_store<F>(w, kt);
+  fe_store<F>(w + F::NW, x);
+  store_words<F>(rec + 2 * F::NW, w);
+}
+
+// canonical (x | y) -> Niels records
+template <class F>
+__global__ void __launch_bounds__(256) k_te_points_to_niels(uint32_t* out, const uint32_t* in, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p;
+  load_affine<F>(p, in + (size_t)i * 2 * F::NW, 0);
+  Fe<F> x, y;
+  fe_to_mont(x, p.x);
+  fe_to_mont(y, p.y);
+  te_store_niels<F>(out + (size_t)i * 4 * F::NW, x, y);
+}
+
+// Niels records -> canonical (x | y):  x is stored, y = (y - x) + x
+template <class F>
+__global__ void __launch_bounds__(256) k_te_points_from_niels(uint32_t* out, const uint32_t* in, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<F> ym, yp, kt, x, y, t;
+  load_fe4<F>(ym, yp, kt, x, in + (size_t)i * 4 * F::NW);
+  fe_add(y, ym, x);
+  uint32_t w[2 * F::NW];
+  fe_from_mont(t, x);
+  fe_to_canon_words<F>(w, t);
+  fe_from_mont(t, y);
+  fe_to_canon_words<F>(w + F::NW, t);
+  store_words<F>(out + (size_t)i * 2 * F::NW, w);
+}
+
+template <class F>
+__device__ __forceinline__ void te_from_affine(TeExt<F>& p, const Affine<F>& a) {
+  p.X = a.x;
+  p.Y = a.y;
+  fe_set_const<F>(p.Z, F::ONE);
+  fe_mul(p.T, a.x, a.y);
+}
+
+template <class F>
+__device__ __forceinline__ void te_to_affine_mont(Affine<F>& a, const TeExt<F>& p) {
+  Fe<F> zi;
+  fe_inverse(zi, p.Z);
+  fe_mul(a.x, p.X, zi);
+  fe_mul(a.y, p.Y, zi);
+}
+
+// table[k * GEN_TABLE + w] = w * base_k as affine [x | y] records (w = 0 -> the identity (0, 1))
+template <class F>
+__global__ void __launch_bounds__(128) k_te_gen_table(uint32_t* table, const uint32_t* bases) {
+  constexpr int RW = 2 * F::NW;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= GEN_WINDOWS * GEN_TABLE) return;
+  uint32_t k = t / GEN_TABLE, w = t % GEN_TABLE;
+  Affine<F> base;
+  load_affine<F>(base, bases + (size_t)k * RW, 0);
+  TeExt<F> b, acc, tmp;
+  te_from_affine(b, base);
+  te_set_zero(acc);
+  for (int bit = GEN_BITS - 1; bit >= 0; bit--) {
+    te_add(tmp, acc, acc);
+    acc = tmp;
+    if ((w >> bit) & 1u) {
+      te_add(tmp, acc, b);
+      acc = tmp;
+    }
+  }
+  Affine<F> a;
+  te_to_affine_mont(a, acc);
+  store_affine<F>(table + (size_t)t * RW, a, false);
+}
+
+template <class F>
+__global__ void __launch_bounds__(128) k_te_gen_points(uint32_t* out, const uint32_t* table, uint32_t n, uint64_t seed) {
+  constexpr int RW = 2 * F::NW;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t a = splitmix64(seed, i);
+  TeExt<F> acc, tmp, q;
+  te_set_zero(acc);
+#pragma unroll 1
+  for (int k = 0; k < GEN_WINDOWS; k++) {
+    uint32_t w = (uint32_t)(a >> (GEN_BITS * k)) & (GEN_TABLE - 1);
+    if (w == 0) continue;
+    Affine<F> p;
+    load_affine<F>(p, table + ((size_t)k * GEN_TABLE + w) * RW, 0);
+    te_from_affine(q, p);
+    te_add(tmp, acc, q);
+    acc = tmp;
+  }
+  Affine<F> r;
+  te_to_affine_mont(r, acc);
+  te_store_niels<F>(out + (size_t)i * 4 * F::NW, r.x, r.y);
+}
+
 }  // namespace msmz

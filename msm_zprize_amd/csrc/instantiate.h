@@ -1,44 +1,80 @@
-// Explicit-instantiation lists: each kernel family is compiled in its own translation unit
-// (kern_*.hip) so the build parallelizes; msmz.hip only sees `extern template` declarations.
+// Explicit-instantiation lists: each (kernel family, curve) pair is compiled in its own translation
+// unit (kern_<family>.hip with -DMSMZ_CURVE=<id>) so the build parallelizes; msmz.hip only sees
+// `extern template` declarations.
 #pragma once
 #include "gen_kernels.h"
 #include "kernels.h"
 
-#define MSMZ_WEIERSTRASS_FIELDS(X) X(Bls377Fp, Bls377Fr)
+// curve ids as in include/msmz.h
+#if !defined(MSMZ_CURVE) || MSMZ_CURVE == 0
+#define MSMZ_W0(X) X(Bls377Fp, Bls377Fr)
+#else
+#define MSMZ_W0(X)
+#endif
+#if !defined(MSMZ_CURVE) || MSMZ_CURVE == 1
+#define MSMZ_W1(X) X(PallasFp, PallasFr)
+#else
+#define MSMZ_W1(X)
+#endif
+#if !defined(MSMZ_CURVE) || MSMZ_CURVE == 2
+#define MSMZ_W2(X) X(Bls381Fp, Bls381Fr)
+#else
+#define MSMZ_W2(X)
+#endif
+#if !defined(MSMZ_CURVE) || MSMZ_CURVE == 3
+#define MSMZ_T3(X) X(Ed377Fp, Ed377Fr)
+#else
+#define MSMZ_T3(X)
+#endif
+#define MSMZ_WEIERSTRASS_FIELDS(X) MSMZ_W0(X) MSMZ_W1(X) MSMZ_W2(X)
+#define MSMZ_TE_FIELDS(X) MSMZ_T3(X)
 
 #define MSMZ_BATCH_T 256
+#define MSMZ_BATCH_OCC 2
+#define MSMZ_BATCH_BMAX 16
 
-// (T, OCC = min waves per SIMD, BMAX = max pairs per thread) variants of the batch-add kernel
-#define MSMZ_BATCH_VARIANTS(Y, F, PFX) \
-  Y(F, 256, 2, 16, PFX) Y(F, 256, 3, 16, PFX) Y(F, 256, 4, 16, PFX) Y(F, 512, 2, 8, PFX) Y(F, 512, 4, 8, PFX)
+#define MSMZ_INST_BATCH(F, Fr, PFX)                                                                               \
+  PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, true, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(              \
+      uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, int, MsmMeta*); \
+  PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, false, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(             \
+      uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, int, MsmMeta*);
 
-#define MSMZ_INST_BATCH_ONE(F, T, OCC, BMAX, PFX)                                                                     \
-  PFX template __global__ void k_batch_add<F, T, true, OCC, BMAX>(uint32_t*, const uint32_t*, const uint32_t*,        \
-                                                                  const uint32_t*, const uint32_t*, uint32_t, int, int, \
-                                                                  MsmMeta*);                                          \
-  PFX template __global__ void k_batch_add<F, T, false, OCC, BMAX>(uint32_t*, const uint32_t*, const uint32_t*,       \
-                                                                   const uint32_t*, const uint32_t*, uint32_t, int,    \
-                                                                   int, MsmMeta*);
+#define MSMZ_INST_POLICY(P, PFX)                                                                                 \
+  PFX template __global__ void k_reduce_next<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
+                                                const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int);   \
+  PFX template __global__ void k_bucket_accumulate<P>(uint32_t*, const uint32_t*, const uint32_t*,               \
+                                                      const uint32_t*, const uint32_t*, uint32_t, uint32_t);
 
-#define MSMZ_INST_BATCH(F, Fr, PFX) MSMZ_BATCH_VARIANTS(MSMZ_INST_BATCH_ONE, F, PFX)
+#define MSMZ_INST_REDUCE(F, Fr, PFX)                                                                              \
+  PFX template __global__ void k_reduce_first<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
+                                                 const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,   \
+                                                 uint32_t);                                                       \
+  MSMZ_INST_POLICY(WeierPolicy<F>, PFX)
 
-#define MSMZ_INST_REDUCE(F, Fr, PFX)                                                                                   \
-  PFX template __global__ void k_reduce_first<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,               \
-                                                 const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,        \
-                                                 uint32_t);                                                            \
-  PFX template __global__ void k_reduce_next<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, uint32_t,      \
-                                                uint32_t, uint32_t, uint32_t, int);
+#define MSMZ_INST_REDUCE_TE(F, Fr, PFX) MSMZ_INST_POLICY(TePolicy<F>, PFX)
 
-#define MSMZ_INST_MISC(F, Fr, PFX)                                                                                     \
-  PFX template __global__ void k_points_to_mont<F>(uint32_t*, const uint32_t*, const uint8_t*, uint32_t, int);         \
-  PFX template __global__ void k_points_from_mont<F>(uint32_t*, const uint32_t*, uint32_t);                            \
-  PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int);          \
-  PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int);         \
+#define MSMZ_INST_SCALAR(Fr, PFX)                                                                                 \
+  PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int); \
   PFX template __global__ void k_gen_scalars<Fr>(uint32_t*, uint32_t, uint64_t);
 
-#define MSMZ_INST_GEN(F, Fr, PFX)                                                                \
-  PFX template __global__ void k_gen_table<F>(uint32_t*, const uint32_t*);                       \
+#define MSMZ_INST_MISC(F, Fr, PFX)                                                                                \
+  PFX template __global__ void k_points_to_mont<F>(uint32_t*, const uint32_t*, const uint8_t*, uint32_t, int);    \
+  PFX template __global__ void k_points_from_mont<F>(uint32_t*, const uint32_t*, uint32_t);                       \
+  PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int); \
+  MSMZ_INST_SCALAR(Fr, PFX)
+
+#define MSMZ_INST_MISC_TE(F, Fr, PFX)                                                              \
+  PFX template __global__ void k_te_points_to_niels<F>(uint32_t*, const uint32_t*, uint32_t);      \
+  PFX template __global__ void k_te_points_from_niels<F>(uint32_t*, const uint32_t*, uint32_t);    \
+  MSMZ_INST_SCALAR(Fr, PFX)
+
+#define MSMZ_INST_GEN(F, Fr, PFX)                                                \
+  PFX template __global__ void k_gen_table<F>(uint32_t*, const uint32_t*);       \
   PFX template __global__ void k_gen_points<F>(uint32_t*, const uint32_t*, uint32_t, uint64_t, int);
+
+#define MSMZ_INST_GEN_TE(F, Fr, PFX)                                             \
+  PFX template __global__ void k_te_gen_table<F>(uint32_t*, const uint32_t*);    \
+  PFX template __global__ void k_te_gen_points<F>(uint32_t*, const uint32_t*, uint32_t, uint64_t);
 
 #define MSMZ_EXTERN extern
 #define MSMZ_DEFINE

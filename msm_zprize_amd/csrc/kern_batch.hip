@@ -1,4 +1,4 @@
-// Device code of one kernel family (see instantiate.h).
+// Device code of one kernel family for the curve selected with -DMSMZ_CURVE (see instantiate.h).
 #include "instantiate.h"
 namespace msmz {
 #define X(F, Fr) MSMZ_INST_BATCH(F, Fr, MSMZ_DEFINE)

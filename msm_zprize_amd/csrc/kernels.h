@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* coun
       s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
       s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
     }
-    if (GLV) {
+    if constexpr (GLV) {
       uint32_t h[2][4], neg[2];
       glv_decompose<Fr>(h[0], h[1], neg[0], neg[1], s);
 #pragma unroll
@@ -252,6 +252,7 @@ __device__ __forceinline__ uint32_t scan_value(const uint32_t* in, uint32_t g, u
   if (g >= n) return 0;
   if (mode == 0) return in[g];
   uint32_t s = in[g + 1] - in[g];
+  if (mode == 2) return (s + 63u) >> 6;   // chunks of ACC_CHUNK = 64 entries (msmBasic accumulation)
   uint32_t m = 1u << r;
   return (s + m - 1) >> (r + 1);
 }
@@ -372,9 +373,7 @@ static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t
 //                          by coarse bin, writes (fine | negate | index) words (4 B) in contiguous runs
 //   k_sort_fine            one workgroup per coarse bin: LDS histogram of its <= 256 buckets -> bucket
 //                          offsets `off`, then places every reference at its final sorted position
-constexpr int SORT_FB_MAX = 8;
-constexpr int SORT_IDX_BITS = 23;
-constexpr uint32_t SORT_IDX_MASK = (1u << SORT_IDX_BITS) - 1;
+constexpr int SORT_FB_MAX = 8;     // fine bits when the index needs <= 23 bits; 31 - idx_bits in general
 constexpr int COARSE_T = 256;
 constexpr int COARSE_ITEMS = 32;
 constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // 8192 entries per workgroup
@@ -383,7 +382,7 @@ constexpr int COARSE_MAX_BINS = 512;                  // bins per window the LDS
 template <int NBINS_MAX>
 static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* packed_out, uint32_t* bin_cursor,
                                                                     const uint32_t* bin_base, const uint32_t* digits,
-                                                                    uint32_t M, int fb, uint32_t ncb) {
+                                                                    uint32_t M, int fb, uint32_t ncb, int idx_bits) {
   __shared__ uint32_t s_cnt[NBINS_MAX];     // entries of this tile per bin, then exclusive scan
   __shared__ uint32_t s_gbase[NBINS_MAX];   // global base of this tile's run in each bin
   __shared__ uint32_t s_stage[COARSE_TILE];
@@ -406,7 +405,7 @@ static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* pa
       if (l != 0) {
         const uint32_t idx = l - 1;
         bin[j] = (uint16_t)(idx >> fb);
-        val[j] = ((idx & ((1u << fb) - 1u)) << (SORT_IDX_BITS + 1)) | ((d >> 31) << SORT_IDX_BITS) | i;
+        val[j] = ((idx & ((1u << fb) - 1u)) << (idx_bits + 1)) | ((d >> 31) << idx_bits) | i;
         rank[j] = atomicAdd(&s_cnt[bin[j]], 1u);
       }
     }
@@ -449,7 +448,7 @@ static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* pa
 // (+ running maximum bucket size); phase B: every entry goes to its final position.
 static __global__ void __launch_bounds__(256) k_sort_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
                                                           const uint32_t* packed, const uint32_t* bin_base, int fb,
-                                                          uint32_t n_bins) {
+                                                          uint32_t n_bins, int idx_bits) {
   __shared__ uint32_t s_cnt[1 << SORT_FB_MAX];
   __shared__ uint32_t s_cur[1 << SORT_FB_MAX];
   __shared__ uint32_t s_wave[4];
@@ -458,7 +457,7 @@ static __global__ void __launch_bounds__(256) k_sort_fine(uint32_t* refs, uint32
   const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
   if (threadIdx.x < nfine) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t p = begin + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[packed[p] >> (SORT_IDX_BITS + 1)], 1u);
+  for (uint32_t p = begin + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
   __syncthreads();
   const uint32_t c = threadIdx.x < nfine ? s_cnt[threadIdx.x] : 0;
   uint32_t total;
@@ -472,8 +471,8 @@ static __global__ void __launch_bounds__(256) k_sort_fine(uint32_t* refs, uint32
   __syncthreads();
   for (uint32_t p = begin + threadIdx.x; p < end; p += 256) {
     const uint32_t v = packed[p];
-    const uint32_t pos = atomicAdd(&s_cur[v >> (SORT_IDX_BITS + 1)], 1u);
-    refs[pos] = (v & SORT_IDX_MASK) | (((v >> SORT_IDX_BITS) & 1u) << 31);
+    const uint32_t pos = atomicAdd(&s_cur[v >> (idx_bits + 1)], 1u);
+    refs[pos] = (v & ((1u << idx_bits) - 1u)) | (((v >> idx_bits) & 1u) << 31);
   }
 }
 
@@ -746,6 +745,96 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   }
 }
 
+// ------------------------------------------------------------------------------------------------ group policies
+// The bucket accumulation of the msmBasic path and the bucket reduction are written once over a small
+// "group policy": accumulator type + how to fold an input point record into it.
+//   WeierPolicy : XYZZ accumulators, inputs = affine records [x | y] (2*NW words)
+//   TePolicy    : extended twisted-Edwards accumulators, inputs = Niels records [y-x | y+x | 2dxy] (3*NW words)
+template <class F_>
+struct WeierPolicy {
+  using F = F_;
+  using Acc = Xyzz<F>;
+  static constexpr int IN_WORDS = 2 * F::NW;
+  static constexpr int ACC_WORDS = 4 * F::NW;
+  static __device__ __forceinline__ void zero(Acc& a) { xyzz_set_inf(a); }
+  static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { xyzz_add(r, a, b); }
+  static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { xyzz_dbl(r, a); }
+  static __device__ __forceinline__ void madd(Acc& r, const Acc& a, const uint32_t* rec, uint32_t neg) {
+    Affine<F> p;
+    bool inf = load_affine<F>(p, rec, neg);
+    xyzz_madd(r, a, p, inf);
+  }
+  static __device__ __forceinline__ void load(Acc& a, const uint32_t* rec) { load_xyzz<F>(a, rec); }
+  static __device__ __forceinline__ void store(uint32_t* rec, const Acc& a) { store_xyzz<F>(rec, a); }
+};
+
+template <class F>
+__device__ __forceinline__ void load_fe4(Fe<F>& a, Fe<F>& b, Fe<F>& c, Fe<F>& d, const uint32_t* rec) {
+  uint32_t w[2 * F::NW];
+  load_words<F>(w, rec);
+  fe_unpack<F>(a, w);
+  fe_unpack<F>(b, w + F::NW);
+  load_words<F>(w, rec + 2 * F::NW);
+  fe_unpack<F>(c, w);
+  fe_unpack<F>(d, w + F::NW);
+}
+
+template <class F_>
+struct TePolicy {
+  using F = F_;
+  using Acc = TeExt<F>;
+  static constexpr int IN_WORDS = 4 * F::NW;   // Niels record padded to 4 field elements (16-byte aligned loads)
+  static constexpr int ACC_WORDS = 4 * F::NW;
+  static __device__ __forceinline__ void zero(Acc& a) { te_set_zero(a); }
+  static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { te_add(r, a, b); }
+  static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { te_add(r, a, a); }
+  static __device__ __forceinline__ void madd(Acc& r, const Acc& a, const uint32_t* rec, uint32_t neg) {
+    TeNiels<F> n;
+    Fe<F> pad;
+    load_fe4<F>(n.ym, n.yp, n.kt, pad, rec);
+    te_madd(r, a, n, neg);
+  }
+  static __device__ __forceinline__ void load(Acc& a, const uint32_t* rec) { load_fe4<F>(a.X, a.Y, a.Z, a.T, rec); }
+  static __device__ __forceinline__ void store(uint32_t* rec, const Acc& a) {
+    uint32_t w[2 * F::NW];
+    fe_store<F>(w, a.X);
+    fe_store<F>(w + F::NW, a.Y);
+    store_words<F>(rec, w);
+    fe_store<F>(w, a.Z);
+    fe_store<F>(w + F::NW, a.T);
+    store_words<F>(rec + 2 * F::NW, w);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ msmBasic accumulation
+// Bucket accumulation without batch inversion (msm-basic.ts:106-128: addMixed / subMixed into projective
+// or extended buckets).  The sorted reference list of every bucket is cut into chunks of CH entries
+// (cscan = exclusive scan of ceil(size / CH), scan mode 2); one thread folds one chunk into an accumulator.
+constexpr int ACC_CHUNK = 64;
+
+template <class P>
+__global__ void __launch_bounds__(128) k_bucket_accumulate(uint32_t* partial, const uint32_t* points,
+                                                           const uint32_t* refs, const uint32_t* off,
+                                                           const uint32_t* cscan, uint32_t nb, uint32_t n_chunks) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_chunks) return;
+  uint32_t lo = 0, hi = nb;   // cscan[lo] <= t < cscan[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (cscan[mid] <= t) lo = mid; else hi = mid;
+  }
+  const uint32_t start = off[lo] + (t - cscan[lo]) * ACC_CHUNK;
+  const uint32_t end = min(start + ACC_CHUNK, off[lo + 1]);
+  typename P::Acc acc, tmp;
+  P::zero(acc);
+  for (uint32_t p = start; p < end; p++) {
+    const uint32_t rf = refs[p];
+    P::madd(tmp, acc, points + (size_t)(rf & REF_IDX) * P::IN_WORDS, rf >> 31);
+    acc = tmp;
+  }
+  P::store(partial + (size_t)t * P::ACC_WORDS, acc);
+}
+
 // ------------------------------------------------------------------------------------------------ reduce
 // Bucket sum of global bucket g after all tree rounds: empty -> infinity; one element -> the original
 // point; otherwise slot[off[g]].
@@ -797,44 +886,55 @@ __global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* 
   store_xyzz<F>(tris + (size_t)t * 4 * F::NW, tri);
 }
 
-// Level >= 2 on XYZZ inputs: for group A of S consecutive entries (per window, n_in entries):
+// Level >= 2 on accumulator inputs: for group A of S consecutive entries (per window, n_in entries):
 //   row'_A = sum_b row[AS+b],  tri'_A = sum_b b*row[AS+b],  C'_A = sum_b C[AS+b] + 2^shift * tri'_A
 // where 2^shift is the product of all previous group sizes.  After the last level (one entry per
 // window)  sum_i i*B_i = C  and  sum_i B_i = row.
-template <class F>
+// With c_in == nullptr this is also the FIRST level of the msmBasic path: entry i of window k is then
+// the sum of the partial accumulators  rows_in[cscan[kL+i] .. cscan[kL+i+1])  (cscan != nullptr).
+template <class P>
 __global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
-                                                     const uint32_t* c_in, uint32_t n_in, uint32_t S, uint32_t groups,
-                                                     uint32_t total, int shift) {
-  constexpr int XW = 4 * F::NW;
+                                                     const uint32_t* c_in, const uint32_t* cscan, uint32_t n_in,
+                                                     uint32_t S, uint32_t groups, uint32_t total, int shift) {
+  constexpr int XW = P::ACC_WORDS;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t k = t / groups, A = t - k * groups;
   size_t base = (size_t)k * n_in + (size_t)A * S;
-  Xyzz<F> run, tri, cs, tmp, p;
-  xyzz_set_inf(run);
-  xyzz_set_inf(tri);
-  xyzz_set_inf(cs);
+  typename P::Acc run, tri, cs, tmp, p;
+  P::zero(run);
+  P::zero(tri);
+  P::zero(cs);
   for (uint32_t b = S; b-- > 0;) {
     if (A * S + b >= n_in) continue;
-    load_xyzz<F>(p, c_in + (base + b) * XW);
-    xyzz_add(tmp, cs, p);
-    cs = tmp;
-    load_xyzz<F>(p, rows_in + (base + b) * XW);
-    xyzz_add(tmp, run, p);
-    run = tmp;
+    if (c_in != nullptr) {
+      P::load(p, c_in + (base + b) * XW);
+      P::add(tmp, cs, p);
+      cs = tmp;
+    }
+    if (cscan != nullptr) {
+      for (uint32_t q = cscan[base + b]; q < cscan[base + b + 1]; q++) {
+        P::load(p, rows_in + (size_t)q * XW);
+        P::add(tmp, run, p);
+        run = tmp;
+      }
+    } else {
+      P::load(p, rows_in + (base + b) * XW);
+      P::add(tmp, run, p);
+      run = tmp;
+    }
     if (b >= 1) {
-      xyzz_add(tmp, tri, run);
+      P::add(tmp, tri, run);
       tri = tmp;
     }
   }
-  // note: tri accumulated run after including entry b, for b >= 1  ->  sum_b b*row_b
   for (int s = 0; s < shift; s++) {
-    xyzz_dbl(tmp, tri);
+    P::dbl(tmp, tri);
     tri = tmp;
   }
-  xyzz_add(tmp, cs, tri);
-  store_xyzz<F>(rows_out + (size_t)t * XW, run);
-  store_xyzz<F>(c_out + (size_t)t * XW, tmp);
+  P::add(tmp, cs, tri);
+  P::store(rows_out + (size_t)t * XW, run);
+  P::store(c_out + (size_t)t * XW, tmp);
 }
 
 }  // namespace msmz

@@ -4,28 +4,44 @@ namespace msmz {
 #define X(F, Fr) MSMZ_INST_BATCH(F, Fr, MSMZ_EXTERN) MSMZ_INST_REDUCE(F, Fr, MSMZ_EXTERN) MSMZ_INST_MISC(F, Fr, MSMZ_EXTERN) MSMZ_INST_GEN(F, Fr, MSMZ_EXTERN)
 MSMZ_WEIERSTRASS_FIELDS(X)
 #undef X
+#define X(F, Fr) MSMZ_INST_REDUCE_TE(F, Fr, MSMZ_EXTERN) MSMZ_INST_MISC_TE(F, Fr, MSMZ_EXTERN) MSMZ_INST_GEN_TE(F, Fr, MSMZ_EXTERN)
+MSMZ_TE_FIELDS(X)
+#undef X
 }  // namespace msmz
 #include "engine.h"
 
 namespace msmz {
 
-template <class Cfg>
-static int run_weierstrass(Engine<Cfg>& e, const Handle& pts, const uint32_t* d_scalars, uint64_t n,
-                           const msmz_opts& opt, uint8_t* out, int* out_inf, msmz_log* log) {
-  if (opt.buckets == MSMZ_BUCKETS_PROJECTIVE) return MSMZ_ERR_UNSUPPORTED;
-  return e.msm_weierstrass_affine(pts, d_scalars, n, opt, out, out_inf, log);
-}
-
-struct CfgBls377 {
-  using F = Bls377Fp;
-  using Fr = Bls377Fr;
+// Curve configurations: which field structs, which MSM paths.
+template <class F_, class Fr_>
+struct WeierCfg {
+  using F = F_;
+  using Fr = Fr_;
+  static constexpr bool TE = false;
   static constexpr bool HAS_ENDO = true;
-  static constexpr int BATCH_T = MSMZ_BATCH_T;
-  static int run_msm(Engine<CfgBls377>& e, const Handle& p, const uint32_t* s, uint64_t n, const msmz_opts& o,
+  static int run_msm(Engine<WeierCfg>& e, const Handle& p, const uint32_t* s, uint64_t n, const msmz_opts& o,
                      uint8_t* out, int* oi, msmz_log* log) {
-    return run_weierstrass(e, p, s, n, o, out, oi, log);
+    if (o.buckets == MSMZ_BUCKETS_PROJECTIVE) return e.msm_weierstrass_projective(p, s, n, o, out, oi, log);
+    return e.msm_weierstrass_affine(p, s, n, o, out, oi, log);
   }
 };
+
+template <class F_, class Fr_>
+struct TeCfg {
+  using F = F_;
+  using Fr = Fr_;
+  static constexpr bool TE = true;
+  static constexpr bool HAS_ENDO = false;
+  static int run_msm(Engine<TeCfg>& e, const Handle& p, const uint32_t* s, uint64_t n, const msmz_opts& o,
+                     uint8_t* out, int* oi, msmz_log* log) {
+    return e.msm_twisted_edwards(p, s, n, o, out, oi, log);
+  }
+};
+
+using CfgBls377 = WeierCfg<Bls377Fp, Bls377Fr>;
+using CfgPallas = WeierCfg<PallasFp, PallasFr>;
+using CfgBls381 = WeierCfg<Bls381Fp, Bls381Fr>;
+using CfgEd377 = TeCfg<Ed377Fp, Ed377Fr>;
 
 }  // namespace msmz
 
@@ -64,6 +80,32 @@ static int point_add_w(const uint8_t* a, int ai, const uint8_t* b, int bi, uint8
   return MSMZ_OK;
 }
 
+template <class F>
+static int point_add_te(const uint8_t* a, const uint8_t* b, uint8_t* out, int* oi) {
+  constexpr int NW = F::NW;
+  auto load = [](TeExt<F>& p, const uint8_t* xy) {
+    uint32_t w[2 * NW];
+    memcpy(w, xy, sizeof(w));
+    Fe<F> x, y;
+    fe_unpack<F>(x, w);
+    fe_unpack<F>(y, w + NW);
+    fe_to_mont(p.X, x);
+    fe_to_mont(p.Y, y);
+    fe_set_const<F>(p.Z, F::ONE);
+    fe_mul(p.T, p.X, p.Y);
+  };
+  if (!a || !b) return MSMZ_ERR_ARG;   // twisted Edwards has no infinity flag: the identity is (0, 1)
+  TeExt<F> p, q, r;
+  load(p, a);
+  load(q, b);
+  te_add(r, p, q);
+  uint32_t w[2 * NW];
+  te_to_affine_canon<F>(w, r);
+  memcpy(out, w, sizeof(w));
+  *oi = 0;
+  return MSMZ_OK;
+}
+
 extern "C" {
 
 const char* msmz_strerror(int status) {
@@ -99,13 +141,15 @@ int msmz_create(msmz_ctx** out, int curve_id, const int* device_ids, int n_devic
   if (device_ids[0] < 0 || device_ids[0] >= count) return MSMZ_ERR_ARG;
   IEngine* eng = nullptr;
   int st = MSMZ_ERR_UNSUPPORTED;
+  auto make = [&](auto* e) {
+    st = e->init();
+    eng = e;
+  };
   switch (curve_id) {
-    case MSMZ_BLS12_377_G1: {
-      auto* e = new Engine<CfgBls377>(device_ids[0]);
-      st = e->init();
-      eng = e;
-      break;
-    }
+    case MSMZ_BLS12_377_G1: make(new Engine<CfgBls377>(device_ids[0])); break;
+    case MSMZ_PALLAS: make(new Engine<CfgPallas>(device_ids[0])); break;
+    case MSMZ_BLS12_381_G1: make(new Engine<CfgBls381>(device_ids[0])); break;
+    case MSMZ_ED_ON_BLS12_377: make(new Engine<CfgEd377>(device_ids[0])); break;
     default: break;
   }
   if (st != MSMZ_OK) {
@@ -157,6 +201,9 @@ int msmz_point_add(int curve_id, const uint8_t* a, int ai, const uint8_t* b, int
   if (!out || !oi || (!a && !ai) || (!b && !bi)) return MSMZ_ERR_ARG;
   switch (curve_id) {
     case MSMZ_BLS12_377_G1: return point_add_w<Bls377Fp>(a, ai, b, bi, out, oi);
+    case MSMZ_PALLAS: return point_add_w<PallasFp>(a, ai, b, bi, out, oi);
+    case MSMZ_BLS12_381_G1: return point_add_w<Bls381Fp>(a, ai, b, bi, out, oi);
+    case MSMZ_ED_ON_BLS12_377: return point_add_te<Ed377Fp>(a, b, out, oi);
     default: return MSMZ_ERR_UNSUPPORTED;
   }
 }

@@ -1,67 +1,123 @@
 """Parity of the HIP MSM (through the C ABI) against the oracle -- the build's version of the
-reference's integration test src/msm.test.ts:65-82 (msmUnsafe == bigint msm for N = 2^0..2^12) and
-of its known-answer smoke tests (scripts/zprize23/submission-test-bls377.ts)."""
+reference's integration test src/msm.test.ts:24-118 (for ed-on-bls12-377, pallas, bls12-377, bls12-381:
+msmUnsafe == msmProjective == bigint msm for N = 2^0 .. 2^12) and of its known-answer smoke tests
+(scripts/zprize23/submission-test-bls377.ts, submission-test.ts).  All comparisons are bit-exact on
+the canonical affine result."""
 import random
 
 import pytest
 
 from oracle import bigint_ref as B
+from oracle import c_oracle
 from oracle import params as P
 from oracle import prng
 
 pytestmark = pytest.mark.gpu
 
+WEIER = ["bls12-377", "pallas", "bls12-381"]
+
 
 @pytest.fixture(scope="module")
-def bls377():
+def curves():
     import msm_zprize_amd as m
     m.startThreads()
-    curve = m.Weierstrass.create(m.curves.bls12377Params)
-    yield curve
-    curve.close()
+    cache = {}
+
+    def get(label):
+        if label not in cache:
+            params = m.curves.BY_LABEL[label]
+            cache[label] = (m.Weierstrass if params["kind"] == "weierstrass" else m.TwistedEdwards).create(params)
+        return cache[label]
+
+    yield get
+    for c in cache.values():
+        c.close()
 
 
-def _oracle_msm(params, scalars, pts):
-    Pr = B.ProjectiveWeierstrass(params)
-    r = B.msm(Pr, scalars, [Pr.from_affine((p["x"], p["y"], p["isZero"])) for p in pts])
-    x, y, z = Pr.to_affine(r)
-    return {"x": x, "y": y, "isZero": z}
+def _strip(p):
+    return {"x": p["x"], "y": p["y"], "isZero": bool(p.get("isZero", False))}
 
 
-def test_random_inputs_match_their_spec(bls377):
-    """device generators == their documented pure functions of (seed, index)"""
-    c = P.BLS12_377
-    A = B.AffineWeierstrass(c)
+def _oracle(label, scalars, pts):
+    return c_oracle.msm(P.CURVES[label], scalars, pts)
+
+
+@pytest.mark.parametrize("label", WEIER + ["ed-on-bls12-377"])
+def test_random_inputs_match_their_spec(curves, label):
+    """device generators == their documented pure functions of (seed, index); points on the curve"""
+    curve = curves(label)
+    c = P.CURVES[label]
     n, seed = 300, 12345
-    pts = bls377.Parallel.randomPointsFast(n, seed)
-    got = bls377.Affine.toBigints(pts)
+    pts = curve.Parallel.randomPointsFast(n, seed)
+    got = curve.Affine.toBigints(pts)
+    if c["kind"] == "weierstrass":
+        A = B.AffineWeierstrass(c)
+        gen = {"x": c["generator"]["x"], "y": c["generator"]["y"], "isZero": False}
+        for p in got:
+            assert A.is_on_curve((p["x"], p["y"], p["isZero"]))
+    else:
+        T = B.TwistedEdwards(c)
+        gen = {"x": c["generator"]["x"], "y": c["generator"]["y"]}
+        for p in got:
+            assert T.is_on_curve(T.from_affine((p["x"], p["y"])))
     for i in [0, 1, 2, 17, 299]:
-        a = prng.point_multiplier(seed, i)
-        x, y, z = A.scale(a, A.one)
-        assert got[i] == {"x": x, "y": y, "isZero": z}, i
-    for p in got:
-        assert A.is_on_curve((p["x"], p["y"], p["isZero"]))
-    sc = bls377.Parallel.randomScalars(n, seed)
-    assert bls377.Scalar.toBigints(sc) == [prng.scalar(seed, i, c["order"]) for i in range(n)]
+        want = c_oracle.scale(c, prng.point_multiplier(seed, i), gen)
+        assert _strip(got[i]) == _strip(want), i
+    sc = curve.Parallel.randomScalars(n, seed)
+    assert curve.Scalar.toBigints(sc) == [prng.scalar(seed, i, c["order"]) for i in range(n)]
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 16, 64, 257, 1024, 4096])
-@pytest.mark.parametrize("glv", [0, 1])
-def test_msm_unsafe_vs_oracle(bls377, n, glv):
+@pytest.mark.parametrize("label", WEIER)
+def test_weierstrass_msm_vs_oracle(curves, label, n):
+    """msm.test.ts:44-82: msmUnsafe (GLV on/off), msm (safe) and msmProjective all equal the bigint MSM"""
+    curve = curves(label)
     seed = 1000 + n
-    pts = bls377.Parallel.randomPointsFast(n, seed)
-    sc = bls377.Parallel.randomScalars(n, seed)
-    want = _oracle_msm(P.BLS12_377, bls377.Scalar.toBigints(sc), bls377.Affine.toBigints(pts))
-    for c in ([0] if n > 300 else [0, 2, 5]):
-        got = bls377.Parallel.msmUnsafe(sc, pts, n, True, {"glv": glv, "c": c})["result"]
-        assert got == want, (n, glv, c)
-    got = bls377.Parallel.msm(sc, pts, n, False, {"glv": glv})["result"]
-    assert got == want
+    pts = curve.Parallel.randomPointsFast(n, seed)
+    sc = curve.Parallel.randomScalars(n, seed)
+    want = _oracle(label, curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
+    for glv in (0, 1):
+        for c in ([0] if n > 300 else [0, 2, 5]):
+            got = curve.Parallel.msmUnsafe(sc, pts, n, True, {"glv": glv, "c": c})["result"]
+            assert got == want, (n, glv, c)
+        assert curve.Parallel.msm(sc, pts, n, False, {"glv": glv})["result"] == want
+    assert curve.Parallel.msmProjective(sc, pts, n)["result"] == want
+    assert curve.Parallel.msmProjective(sc, pts, n, {"c": 7})["result"] == want
     pts.free(); sc.free()
 
 
-def test_known_answer_submission_bls377(bls377):
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 16, 64, 257, 1024, 4096])
+def test_twisted_edwards_msm_vs_oracle(curves, n):
+    """msm.test.ts:85-118"""
+    curve = curves("ed-on-bls12-377")
+    seed = 2000 + n
+    pts = curve.Parallel.randomPointsFast(n, seed)
+    sc = curve.Parallel.randomScalars(n, seed)
+    want = _oracle("ed-on-bls12-377", curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
+    for c in ([0] if n > 300 else [0, 3, 6]):
+        assert _strip(curve.Parallel.msm(sc, pts, n, True, {"c": c})["result"]) == _strip(want), (n, c)
+    pts.free(); sc.free()
+
+
+def test_host_buffer_scalars_and_byte_routes(curves):
+    """scalars handed over as a host buffer (msmz_msm) and points through pointsFromBytes (parallel.ts:97-133)"""
+    curve = curves("bls12-377")
+    n = 500
+    pts = curve.Parallel.randomPointsFast(n, 77)
+    sc = curve.Parallel.randomScalars(n, 78)
+    scalars = curve.Scalar.toBigints(sc)
+    points = curve.Affine.toBigints(pts)
+    want = _oracle("bls12-377", scalars, points)
+    raw = b"".join(s.to_bytes(32, "little") for s in scalars)
+    assert curve.Parallel.msmUnsafe(raw, pts, n, False, {"glv": 0})["result"] == want
+    up = curve.Parallel.pointsFromBigints(points)
+    assert curve.Affine.toBigints(up) == points
+    assert curve.Parallel.msmUnsafe(curve.Parallel.scalarsFromBytes(raw), up, n)["result"] == want
+
+
+def test_known_answer_submission_bls377(curves):
     """scripts/zprize23/submission-test-bls377.ts:6-45: 2P + (q-1)P = P; 1000 x same point."""
+    bls377 = curves("bls12-377")
     q = P.BLS12_377["order"]
     pt = dict(P.KAT_BLS12_377_POINT, isZero=False)
     pts = bls377.Parallel.pointsFromBigints([pt, pt])
@@ -72,9 +128,70 @@ def test_known_answer_submission_bls377(bls377):
     n = 1000
     scalars = [rng.randrange(q) for _ in range(n)]
     same = bls377.Parallel.pointsFromBigints([pt] * n)
-    r2 = bls377.Parallel.msm(bls377.Parallel.scalarsFromBigints(scalars), same, n)["result"]
-    one = bls377.Parallel.pointsFromBigints([pt])
-    r3 = bls377.Parallel.msm(bls377.Parallel.scalarsFromBigints([sum(scalars) % q]), one, 1)["result"]
-    assert r2 == r3
-    A = B.AffineWeierstrass(P.BLS12_377)
-    assert (r3["x"], r3["y"], r3["isZero"]) == A.scale(sum(scalars) % q, (pt["x"], pt["y"], False))
+    for glv in (0, 1):
+        r2 = bls377.Parallel.msm(bls377.Parallel.scalarsFromBigints(scalars), same, n, False, {"glv": glv})["result"]
+        one = bls377.Parallel.pointsFromBigints([pt])
+        r3 = bls377.Parallel.msm(bls377.Parallel.scalarsFromBigints([sum(scalars) % q]), one, 1)["result"]
+        assert r2 == r3
+        assert r3 == c_oracle.scale(P.BLS12_377, sum(scalars) % q, pt)
+    assert bls377.Parallel.msmProjective(bls377.Parallel.scalarsFromBigints(scalars), same, n)["result"] == r3
+
+
+def test_known_answer_submission_ed377(curves):
+    """scripts/zprize23/submission-test.ts:5-20"""
+    curve = curves("ed-on-bls12-377")
+    q = P.ED_ON_BLS12_377["order"]
+    k = P.KAT_ED377_POINT
+    pts = curve.Parallel.pointsFromBigints([k, k])
+    sc = curve.Parallel.scalarsFromBigints([2, q - 1])
+    r = curve.Parallel.msm(sc, pts, 2)["result"]
+    assert (r["x"], r["y"]) == (k["x"], k["y"])
+
+
+def test_safe_path_edge_cases(curves):
+    """batchAddNew semantics (curve-affine.ts:412-447): infinity inputs, P + P, P + (-P), zero scalars"""
+    curve = curves("bls12-377")
+    c = P.BLS12_377
+    q = c["order"]
+    A = B.AffineWeierstrass(c)
+    pt = dict(P.KAT_BLS12_377_POINT, isZero=False)
+    neg = {"x": pt["x"], "y": c["modulus"] - pt["y"], "isZero": False}
+    inf = {"x": 0, "y": 0, "isZero": True}
+    cases = [
+        ([pt, neg], [1, 1]),                      # P + (-P) = 0
+        ([pt, pt, neg, neg], [5, 7, 5, 7]),       # cancels to 0
+        ([inf, pt, inf], [3, 4, 5]),              # infinity inputs are ignored
+        ([pt, pt, pt], [0, 0, 0]),                # all-zero scalars
+        ([pt] * 7, [1] * 7),                      # pure doubling tree
+        ([pt, neg, pt], [q - 1, q - 1, 1]),
+    ]
+    for points, scalars in cases:
+        want = _oracle("bls12-377", scalars, points)
+        pts = curve.Parallel.pointsFromBigints(points)
+        sc = curve.Parallel.scalarsFromBigints(scalars)
+        for glv in (0, 1):
+            for cc in (0, 3):
+                assert curve.Parallel.msm(sc, pts, len(points), False, {"glv": glv, "c": cc})["result"] == want
+        assert curve.Parallel.msmProjective(sc, pts, len(points))["result"] == want
+
+
+def test_unsafe_reports_degenerate_batch(curves):
+    """msmUnsafe on equal points: the reference traps (inverse.ts:198-199); here a status is returned"""
+    import msm_zprize_amd._native as nat
+    curve = curves("bls12-377")
+    pt = dict(P.KAT_BLS12_377_POINT, isZero=False)
+    pts = curve.Parallel.pointsFromBigints([pt, pt])
+    sc = curve.Parallel.scalarsFromBigints([1, 1])
+    with pytest.raises(nat.MsmzError) as e:
+        curve.Parallel.msmUnsafe(sc, pts, 2, False, {"glv": 0})
+    assert e.value.status == 5
+
+
+def test_range_errors(curves):
+    import msm_zprize_amd._native as nat
+    curve = curves("bls12-377")
+    q, p = P.BLS12_377["order"], P.BLS12_377["modulus"]
+    with pytest.raises(nat.MsmzError):
+        curve.Parallel.scalarsFromBigints([q])
+    with pytest.raises(nat.MsmzError):
+        curve.Parallel.pointsFromBigints([{"x": p, "y": 1}])
