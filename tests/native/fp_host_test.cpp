@@ -7,6 +7,7 @@
 #include <iostream>
 #include "../../msm_zprize_amd/csrc/constants_gen.h"
 #include "../../msm_zprize_amd/csrc/fp.h"
+#include "../../msm_zprize_amd/csrc/scalar.h"
 using namespace msmz;
 
 template <int NW> static void parse(const std::string& h, uint32_t* w) {
@@ -41,11 +42,27 @@ template <class F> static void run(const std::string& op, const std::vector<std:
   print<NW>(out);
 }
 
+template <class Fr> static void run_glv(const std::string& h) {
+  uint32_t s[8], s0[4], s1[4], n0, n1;
+  parse<8>(h, s);
+  glv_decompose<Fr>(s0, s1, n0, n1, s);
+  printf("%u:", n0); for (int i = 3; i >= 0; i--) printf("%08x", s0[i]);
+  printf(":%u:", n1); for (int i = 3; i >= 0; i--) printf("%08x", s1[i]);
+  printf("\n");
+}
+
 int main() {
   std::string field, op; int nargs;
   while (std::cin >> field >> op >> nargs) {
     std::vector<std::string> a(nargs);
     for (auto& s : a) std::cin >> s;
+    if (op == "glv") {
+      if (field == "bls377") run_glv<Bls377Fr>(a[0]);
+      else if (field == "bls381") run_glv<Bls381Fr>(a[0]);
+      else if (field == "pallas") run_glv<PallasFr>(a[0]);
+      else printf("ERR\n");
+      continue;
+    }
     if (field == "bls377") run<Bls377Fp>(op, a);
     else if (field == "bls381") run<Bls381Fp>(op, a);
     else if (field == "pallas") run<PallasFp>(op, a);

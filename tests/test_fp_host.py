@@ -24,7 +24,7 @@ FIELDS = {
 
 @pytest.fixture(scope="module")
 def driver():
-    deps = [SRC, os.path.join(ROOT, "msm_zprize_amd", "csrc", "fp.h"), os.path.join(ROOT, "msm_zprize_amd", "csrc", "constants_gen.h")]
+    deps = [SRC, os.path.join(ROOT, "msm_zprize_amd", "csrc", "fp.h"), os.path.join(ROOT, "msm_zprize_amd", "csrc", "scalar.h"), os.path.join(ROOT, "msm_zprize_amd", "csrc", "constants_gen.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", EXE, SRC])
 
@@ -113,3 +113,19 @@ def test_inverse(driver, field):
         # x = a R  ->  a^-1 R = R^2 / x
         assert int(g, 16) == R * R * pow(x, -1, p) % p
     assert driver([f"{field} inv 1 0", f"{field} inv 1 {p:x}"]) == ["ZERO", "ZERO"]
+
+
+@pytest.mark.parametrize("field,params", [("bls377", P.BLS12_377), ("pallas", P.PALLAS), ("bls381", P.BLS12_381)])
+def test_glv_decompose(driver, field, params):
+    """scalar.h glv_decompose (the kernel's code, compiled for the host): s = (+-)s0 + (+-)s1*lambda mod q with
+    |s0|, |s1| < 2^127 -- the relations glv/glv-test.ts:102-125 checks for the wasm `decompose`"""
+    q, lam = params["order"], params["endomorphism"]["lambda_"]
+    rng = random.Random(17)
+    xs = [0, 1, 2, q - 1, q - 2, lam, lam + 1, q - lam, q // 2, (1 << 128) - 1, 1 << 128] + [rng.randrange(q) for _ in range(3000)]
+    got = driver([f"{field} glv 1 {x:x}" for x in xs])
+    for x, g in zip(xs, got):
+        n0, s0, n1, s1 = g.split(":")
+        s0, s1 = int(s0, 16), int(s1, 16)
+        assert s0 < (1 << 127) and s1 < (1 << 127)
+        v = (-s0 if n0 == "1" else s0) + (-s1 if n1 == "1" else s1) * lam
+        assert (v - x) % q == 0, hex(x)
