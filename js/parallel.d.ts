@@ -1,0 +1,31 @@
+// TypeScript declarations for js/parallel.mjs -- the shape of the reference's src/parallel.ts exports.
+export type CurveParams = {
+  label: string; curveId: number; kind: "weierstrass" | "twisted-edwards"; feBytes: number;
+  modulus: bigint; order: bigint; cofactor: bigint; a?: bigint; b?: bigint; d?: bigint;
+  generator: { x: bigint; y: bigint }; endomorphism?: { lambda: bigint; beta: bigint };
+};
+export type BigintPoint = { x: bigint; y: bigint; isZero?: boolean };
+export interface DeviceArray extends Array<DeviceArray> { readonly n: number; readonly kind: "points" | "scalars"; free(): void }
+export type MsmOptions = { c?: number; glv?: boolean | number; useSafeAdditions?: boolean };
+export type MsmResult = { result: BigintPoint; log: any[][]; stats: Record<string, any> };
+export interface ParallelApi {
+  randomPointsFast(n: number, options?: { seed?: bigint | number }): Promise<DeviceArray>;
+  randomScalars(n: number, options?: { seed?: bigint | number }): Promise<DeviceArray>;
+  pointsFromBytes(bytes: Uint8Array, n?: number, isInf?: Uint8Array): Promise<DeviceArray>;
+  scalarsFromBytes(bytes: Uint8Array, n?: number): Promise<DeviceArray>;
+  msm(scalars: DeviceArray | Uint8Array, points: DeviceArray, n: number, verbose?: boolean, options?: MsmOptions): Promise<MsmResult>;
+  msmUnsafe(scalars: DeviceArray | Uint8Array, points: DeviceArray, n: number, verbose?: boolean, options?: MsmOptions): Promise<MsmResult>;
+  msmProjective?(scalars: DeviceArray | Uint8Array, points: DeviceArray, n: number, options?: MsmOptions): Promise<MsmResult>;
+}
+export interface MsmCurve {
+  params: CurveParams; Parallel: ParallelApi;
+  Scalar: { modulus: bigint; sizeInBits: number; readBigint(a: DeviceArray, i?: number): bigint; toBigints(a: DeviceArray, first?: number, count?: number): bigint[]; fromBigints(s: bigint[]): Promise<DeviceArray> };
+  Affine: { size: number; toBigint(p: BigintPoint): BigintPoint; toBigints(a: DeviceArray, first?: number, count?: number): BigintPoint[]; fromBigints(p: BigintPoint[]): Promise<DeviceArray> };
+  Projective: { toAffine(scratch: unknown, affPtr: unknown, result: BigintPoint): BigintPoint; toBigint(r: BigintPoint): BigintPoint };
+  pointAdd(a: BigintPoint, b: BigintPoint): BigintPoint; close(): void;
+}
+export function startThreads(n?: number, deviceId?: number): Promise<number>;
+export function stopThreads(): Promise<void>;
+export const Weierstraß: { create(params: CurveParams): Promise<MsmCurve> };
+export const Weierstrass: { create(params: CurveParams): Promise<MsmCurve> };
+export const TwistedEdwards: { create(params: CurveParams): Promise<MsmCurve> };

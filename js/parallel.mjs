@@ -1,0 +1,182 @@
+// Host-side mirror of the reference's src/parallel.ts for the MI355X engine.
+//
+//   import { Weierstraß, TwistedEdwards, startThreads, stopThreads } from "./parallel.mjs";
+//   await startThreads();
+//   const Curve = await Weierstraß.create(bls12377Params);
+//   let [pointPtr] = await Curve.Parallel.randomPointsFast(N);
+//   let [scalarPtr] = await Curve.Parallel.randomScalars(N);
+//   let { result, log } = await Curve.Parallel.msmUnsafe(scalarPtr, pointPtr, N, true);
+//   Curve.Projective.toAffine(scratch, affPtr, result); Curve.Affine.toBigint(affPtr)  // or toBigint(result)
+//
+// Same names / argument order / promise-returning style as parallel.ts:149-158, 263-271.  The
+// reference's "pointers" into wasm memory become opaque handles to GPU-resident arrays; all the
+// arithmetic happens in HIP behind the N-API addon (napi/msmz_napi.c -> include/msmz.h).  This file is
+// plain ECMAScript (valid TypeScript; declarations in parallel.d.ts) so that it runs without a
+// compile step on the image's node 12.
+import { createRequire } from "module";
+import { dirname, join } from "path";
+import { fileURLToPath } from "url";
+
+const require = createRequire(import.meta.url);
+const here = dirname(fileURLToPath(import.meta.url));
+let addon = null;
+function native() {
+  // fails loudly if the addon / libmsmz.so has not been built: there is no wasm or JS fallback
+  if (addon === null) addon = require(join(here, "msmz_napi.node"));
+  return addon;
+}
+
+let device = null;
+
+/** parallel.ts:291-315.  The "threads" are the GPU's wavefronts: this selects the device. */
+export async function startThreads(n, deviceId) {
+  device = deviceId !== undefined ? deviceId : Number(process.env.LOCAL_RANK || 0);
+  native();
+  return device;
+}
+
+/** parallel.ts:317-320 */
+export async function stopThreads() {
+  device = null;
+}
+
+function bytesToBigint(buf, off, len) {
+  let x = 0n;
+  for (let i = len - 1; i >= 0; i--) x = (x << 8n) | BigInt(buf[off + i]);
+  return x;
+}
+function bigintToBytes(x, len) {
+  const out = Buffer.alloc(len);
+  for (let i = 0; i < len; i++) {
+    out[i] = Number(x & 0xffn);
+    x >>= 8n;
+  }
+  return out;
+}
+
+/** A GPU-resident input array; destructures like the reference's pointer arrays: `let [ptr] = ...` */
+class DeviceArray extends Array {
+  static make(curve, handle, n, kind) {
+    const a = new DeviceArray();
+    a.push(a);
+    Object.defineProperties(a, {
+      curve: { value: curve }, handle: { value: handle, writable: true }, n: { value: n }, kind: { value: kind },
+    });
+    return a;
+  }
+  free() {
+    if (this.handle !== null) native().free(this.curve._ctx, this.handle);
+    this.handle = null;
+  }
+}
+
+function createCurve(params, kind) {
+  if (params.kind !== kind) throw Error(`${params.label} is not a ${kind} curve`);
+  if (device === null) device = Number(process.env.LOCAL_RANK || 0);
+  const N = native();
+  const ctx = N.create(params.curveId, device);
+  const fb = params.feBytes;
+  const te = kind === "twisted-edwards";
+  const curve = { params, _ctx: ctx };
+
+  function decodePoint(buf, off, isInf) {
+    const p = { x: bytesToBigint(buf, off, fb), y: bytesToBigint(buf, off + fb, fb) };
+    if (!te) {
+      p.isZero = !!isInf;
+      if (p.isZero) { p.x = 0n; p.y = 1n; } // bigint/projective-weierstrass.ts:210
+    }
+    return p;
+  }
+
+  async function msmCommon(scalars, points, n, verbose, options, safe, buckets) {
+    options = options || {};
+    const opts = {
+      c: options.c || 0,
+      glv: options.glv !== undefined ? Number(options.glv) : te ? 0 : 1,
+      safe: options.useSafeAdditions !== undefined ? Number(options.useSafeAdditions) : safe,
+      buckets,
+      timing: verbose ? 1 : 0,
+    };
+    const s = scalars instanceof DeviceArray ? scalars.handle : scalars; // Buffer = host scalars
+    const r = N.msm(ctx, points.handle, s, n, fb, opts);
+    const result = decodePoint(r.xy, 0, r.isInf);
+    const log = [[{ n: Math.ceil(Math.log2(n)), K: r.log.K, c: r.log.c }]];
+    for (const [k, v] of Object.entries(r.log.stageMs)) log.push([`${k}... ${v.toFixed(3)}ms`]);
+    return { result, log, stats: r.log };
+  }
+
+  const Parallel = {
+    /** curve-random.ts:14-92, seeded: point i = splitmix64(seed, i) * G */
+    async randomPointsFast(n, { seed = 0x6d736d7an } = {}) {
+      return DeviceArray.make(curve, N.randomPoints(ctx, n, BigInt(seed)), n, "points");
+    },
+    /** curve-random.ts:151-194, seeded */
+    async randomScalars(n, { seed = 0x6d736d7an } = {}) {
+      return DeviceArray.make(curve, N.randomScalars(ctx, n, BigInt(seed)), n, "scalars");
+    },
+    /** parallel.ts:97-112: x||y little-endian canonical */
+    async pointsFromBytes(bytes, n, isInf) {
+      n = n === undefined ? bytes.length / (2 * fb) : n;
+      return DeviceArray.make(curve, N.uploadPoints(ctx, Buffer.from(bytes), isInf ? Buffer.from(isInf) : null, n), n, "points");
+    },
+    /** parallel.ts:114-133: 32 bytes little-endian per scalar */
+    async scalarsFromBytes(bytes, n) {
+      n = n === undefined ? bytes.length / 32 : n;
+      return DeviceArray.make(curve, N.uploadScalars(ctx, Buffer.from(bytes), n), n, "scalars");
+    },
+    /** msm-batched-affine.ts:74-328 with safe additions */
+    msm: (scalars, points, n, verbose = false, options) => msmCommon(scalars, points, n, verbose, options, 1, 0),
+    /** msm-batched-affine.ts:574-586 */
+    msmUnsafe: (scalars, points, n, verbose = false, options) => msmCommon(scalars, points, n, verbose, options, 0, 0),
+  };
+  if (!te) {
+    /** parallel.ts:69-87 */
+    Parallel.msmProjective = (scalars, points, n, options) =>
+      msmCommon(scalars, points, n, true, Object.assign({}, options, { glv: 0 }), 1, 1);
+  }
+
+  curve.Parallel = Parallel;
+  curve.Scalar = {
+    modulus: params.order,
+    sizeInBits: (params.order - 1n).toString(2).length,
+    readBigint: (arr, i = 0) => bytesToBigint(N.downloadScalars(ctx, arr.handle, i, 1), 0, 32),
+    toBigints(arr, first = 0, count = arr.n - first) {
+      const b = N.downloadScalars(ctx, arr.handle, first, count);
+      return Array.from({ length: count }, (_, i) => bytesToBigint(b, 32 * i, 32));
+    },
+    fromBigints: (scalars) => Parallel.scalarsFromBytes(Buffer.concat(scalars.map((s) => bigintToBytes(s, 32)))),
+  };
+  curve.Affine = {
+    size: 2 * fb,
+    /** curve-affine.ts:220-233; accepts an MSM result */
+    toBigint: (p) => p,
+    toBigints(arr, first = 0, count = arr.n - first) {
+      const b = N.downloadPoints(ctx, arr.handle, first, count, fb);
+      return Array.from({ length: count }, (_, i) => {
+        let zero = !te;
+        for (let j = 0; j < 2 * fb && zero; j++) zero = b[2 * fb * i + j] === 0;
+        return decodePoint(b, 2 * fb * i, zero);
+      });
+    },
+    fromBigints(points) {
+      const data = Buffer.concat(points.map((p) => Buffer.concat([bigintToBytes(p.x, fb), bigintToBytes(p.y, fb)])));
+      const inf = Buffer.from(points.map((p) => (p.isZero ? 1 : 0)));
+      return Parallel.pointsFromBytes(data, points.length, inf.some((v) => v) ? inf : null);
+    },
+  };
+  // the reference converts the projective result with Projective.toAffine(scratch, affPtr, result)
+  // (scripts/msm-weierstrass.ts:90-92); results here are already canonical affine points
+  curve.Projective = { toAffine: (_scratch, _affPtr, result) => result, toBigint: (result) => result };
+  curve.Curve = { toBigint: (result) => result };
+  curve.pointAdd = (a, b) => {
+    const enc = (p) => (p.isZero ? null : Buffer.concat([bigintToBytes(p.x, fb), bigintToBytes(p.y, fb)]));
+    const r = N.pointAdd(params.curveId, enc(a), enc(b), fb);
+    return decodePoint(r.xy, 0, r.isInf);
+  };
+  curve.close = () => N.destroy(ctx);
+  return curve;
+}
+
+export const Weierstraß = { create: async (params) => createCurve(params, "weierstrass") };
+export const Weierstrass = Weierstraß;
+export const TwistedEdwards = { create: async (params) => createCurve(params, "twisted-edwards") };

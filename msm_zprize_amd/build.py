@@ -59,5 +59,24 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_napi(force=False, verbose=True):
+    """The N-API addon used by the JavaScript/TypeScript host (js/parallel.mjs)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "napi", "msmz_napi.c")
+    out = os.path.join(root, "js", "msmz_napi.node")
+    inc = "/usr/include/node"
+    if not os.path.exists(os.path.join(inc, "node_api.h")):
+        raise RuntimeError("node_api.h not found: cannot build the N-API addon")
+    if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    cmd = ["gcc", "-O2", "-shared", "-fPIC", f"-I{inc}", src, f"-L{HERE}", "-lmsmz",
+           "-Wl,-rpath,$ORIGIN/../msm_zprize_amd", "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_napi(force="--force" in sys.argv)
