@@ -380,10 +380,15 @@ class Engine : public IEngine {
                          (uint32_t*)nullptr);
       mark(pl);  // 2
       {
-        dim3 grid((M + COARSE_TILE - 1) / COARSE_TILE, K);
+        // persistent tiles: about 4 workgroups per CU over all windows, each loops over its tiles
+        const uint32_t tiles = (M + COARSE_TILE - 1) / COARSE_TILE;
+        uint32_t gx = (coarse_wgs_ + K - 1) / K;
+        if (gx > tiles) gx = tiles;
+        if (gx < 1) gx = 1;
+        dim3 grid(gx, K);
         hipLaunchKernelGGL((k_scatter_coarse<COARSE_MAX_BINS>), grid, dim3(COARSE_T), 0, stream_,
                            packed_.as<uint32_t>(), cursor_.as<uint32_t>(), bins_.as<uint32_t>(),
-                           digits_.as<uint32_t>(), M, fb, ncb, idx_bits);
+                           digits_.as<uint32_t>(), M, fb, ncb, idx_bits, tiles);
       }
       pl.ev_coarse = pl.ei;
       mark(pl);  // 3
@@ -821,6 +826,7 @@ class Engine : public IEngine {
   hipEvent_t ev_[kMaxEvents] = {};
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
+  uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 1024u;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
   DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;

@@ -382,66 +382,100 @@ constexpr int COARSE_MAX_BINS = 512;                  // bins per window the LDS
 template <int NBINS_MAX>
 static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* packed_out, uint32_t* bin_cursor,
                                                                     const uint32_t* bin_base, const uint32_t* digits,
-                                                                    uint32_t M, int fb, uint32_t ncb, int idx_bits) {
-  __shared__ uint32_t s_cnt[NBINS_MAX];     // entries of this tile per bin, then exclusive scan
-  __shared__ uint32_t s_gbase[NBINS_MAX];   // global base of this tile's run in each bin
+                                                                    uint32_t M, int fb, uint32_t ncb, int idx_bits,
+                                                                    uint32_t tiles) {
+  __shared__ uint32_t s_cnt[NBINS_MAX + 1];   // entries of this tile per bin, then exclusive scan (+ total)
+  __shared__ uint32_t s_gbase[NBINS_MAX];     // global address of this tile's run in each bin
   __shared__ uint32_t s_stage[COARSE_TILE];
-  __shared__ uint16_t s_bin[COARSE_TILE];
   __shared__ uint32_t s_wave[COARSE_T / 64];
+  constexpr int VEC = COARSE_ITEMS / 4;       // uint4 loads per thread
   const uint32_t k = blockIdx.y;
   const uint32_t* dk = digits + (size_t)k * M;
-  const uint32_t tile0 = blockIdx.x * COARSE_TILE;
-  for (uint32_t b = threadIdx.x; b < ncb; b += COARSE_T) s_cnt[b] = 0;
-  __syncthreads();
-  uint32_t val[COARSE_ITEMS], rank[COARSE_ITEMS];
-  uint16_t bin[COARSE_ITEMS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  auto load_tile = [&](uint32_t tile, uint4* v) {
+    const uint32_t tile0 = tile * COARSE_TILE;
 #pragma unroll
-  for (int j = 0; j < COARSE_ITEMS; j++) {
-    const uint32_t i = tile0 + j * COARSE_T + threadIdx.x;
-    bin[j] = 0xffff;
-    if (i < M) {
-      const uint32_t d = dk[i];
-      const uint32_t l = d & REF_IDX;
-      if (l != 0) {
-        const uint32_t idx = l - 1;
-        bin[j] = (uint16_t)(idx >> fb);
-        val[j] = ((idx & ((1u << fb) - 1u)) << (idx_bits + 1)) | ((d >> 31) << idx_bits) | i;
-        rank[j] = atomicAdd(&s_cnt[bin[j]], 1u);
+    for (int j = 0; j < VEC; j++) {
+      const uint32_t i = tile0 + (j * COARSE_T + threadIdx.x) * 4;
+      if (i + 3 < M) {
+        v[j] = *reinterpret_cast<const uint4*>(dk + i);
+      } else {
+        v[j].x = i < M ? dk[i] : 0u;
+        v[j].y = i + 1 < M ? dk[i + 1] : 0u;
+        v[j].z = i + 2 < M ? dk[i + 2] : 0u;
+        v[j].w = 0u;
       }
     }
-  }
-  __syncthreads();
-  // reserve the runs in global memory, and scan the counts for the staging order
-  uint32_t my_cnt[NBINS_MAX / COARSE_T], my_sum = 0;
+  };
+
+  uint4 cur[VEC], nxt[VEC];
+  uint32_t tile = blockIdx.x;
+  if (tile < tiles) load_tile(tile, cur);
+  for (; tile < tiles; tile += gridDim.x) {
+    const uint32_t tile0 = tile * COARSE_TILE;
+    const bool more = tile + gridDim.x < tiles;
+    if (more) load_tile(tile + gridDim.x, nxt);   // prefetch the next tile under this tile's LDS phases
+    for (uint32_t b = threadIdx.x; b <= ncb; b += COARSE_T) s_cnt[b] = 0;
+    __syncthreads();
+    uint32_t val[COARSE_ITEMS], rank[COARSE_ITEMS];
+    uint16_t bin[COARSE_ITEMS];
 #pragma unroll
-  for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
-    const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
-    my_cnt[q] = b < ncb ? s_cnt[b] : 0;
-    my_sum += my_cnt[q];
-  }
-  uint32_t total;
-  uint32_t ex = block_exclusive_scan(my_sum, &total, s_wave);
+    for (int j = 0; j < VEC; j++) {
+      const uint32_t d4[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
 #pragma unroll
-  for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
-    const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
-    if (b < ncb) {
-      s_cnt[b] = ex;
-      const uint32_t gb = k * ncb + b;
-      s_gbase[b] = my_cnt[q] ? bin_base[gb] + atomicAdd(&bin_cursor[gb], my_cnt[q]) - ex : 0u;
-      ex += my_cnt[q];
+      for (int q = 0; q < 4; q++) {
+        const int e = j * 4 + q;
+        const uint32_t i = tile0 + (j * COARSE_T + threadIdx.x) * 4 + q;
+        const uint32_t d = d4[q];
+        const uint32_t l = d & REF_IDX;
+        bin[e] = 0xffff;
+        if (l != 0) {
+          const uint32_t idx = l - 1;
+          bin[e] = (uint16_t)(idx >> fb);
+          val[e] = ((idx & ((1u << fb) - 1u)) << (idx_bits + 1)) | ((d >> 31) << idx_bits) | i;
+          rank[e] = atomicAdd(&s_cnt[bin[e]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    // reserve the runs in global memory, and scan the counts for the staging order
+    uint32_t my_cnt[NBINS_MAX / COARSE_T], my_sum = 0;
+#pragma unroll
+    for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
+      const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
+      my_cnt[q] = b < ncb ? s_cnt[b] : 0;
+      my_sum += my_cnt[q];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(my_sum, &total, s_wave);
+#pragma unroll
+    for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
+      const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
+      if (b < ncb) {
+        s_cnt[b] = ex;
+        const uint32_t gb = k * ncb + b;
+        s_gbase[b] = my_cnt[q] ? bin_base[gb] + atomicAdd(&bin_cursor[gb], my_cnt[q]) : 0u;
+        ex += my_cnt[q];
+      }
+    }
+    if (threadIdx.x == 0) s_cnt[ncb] = total;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < COARSE_ITEMS; e++)
+      if (bin[e] != 0xffff) s_stage[s_cnt[bin[e]] + rank[e]] = val[e];
+    __syncthreads();
+    // one wave per bin: each run is a contiguous, coalesced store
+    for (uint32_t b = wave; b < ncb; b += COARSE_T / 64) {
+      const uint32_t r0 = s_cnt[b], r1 = s_cnt[b + 1], g = s_gbase[b];
+      for (uint32_t p = r0 + lane; p < r1; p += 64) packed_out[g + (p - r0)] = s_stage[p];
+    }
+    __syncthreads();
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
     }
   }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < COARSE_ITEMS; j++) {
-    if (bin[j] != 0xffff) {
-      const uint32_t p = s_cnt[bin[j]] + rank[j];
-      s_stage[p] = val[j];
-      s_bin[p] = bin[j];
-    }
-  }
-  __syncthreads();
-  for (uint32_t p = threadIdx.x; p < total; p += COARSE_T) packed_out[s_gbase[s_bin[p]] + p] = s_stage[p];
 }
 
 // One workgroup per coarse bin.  Phase A: histogram of the bin's buckets in LDS -> off[] for those buckets
