@@ -346,6 +346,7 @@ class Engine : public IEngine {
     if ((st = partials_.ensure((size_t)32 * nblocks * 4))) return st;
     MsmMeta* d_meta = meta_.as<MsmMeta>();
     MSMZ_HIP(hipMemsetAsync(d_meta, 0, sizeof(MsmMeta), stream_));
+    if (dbg_) MSMZ_HIP(hipMemcpyAsync(&d_meta->pad, &dbg_, 4, hipMemcpyHostToDevice, stream_));
     // two-level LDS-staged sort when the packed (fine | negate | index) word fits; else per-entry atomics
     const int idx_bits = M <= (1u << 23) ? 23 : 24;
     const int fb_max = 31 - idx_bits;
@@ -435,7 +436,7 @@ class Engine : public IEngine {
 
   // reduce levels on accumulator records: rows in red_[cur*2], C in red_[cur*2+1]; ends with one entry per window
   template <class P>
-  int reduce_levels(const Plan& pl, int& cur, uint32_t n_in, int shift) {
+  int reduce_levels(const Plan& pl, int& cur, uint32_t n_in) {
     constexpr int AW = P::ACC_WORDS;
     int st;
     while (n_in > 1) {
@@ -447,8 +448,7 @@ class Engine : public IEngine {
       uint32_t total = pl.K * g2;
       hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_,
                          red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(), red_[cur * 2].as<uint32_t>(),
-                         red_[cur * 2 + 1].as<uint32_t>(), (const uint32_t*)nullptr, n_in, S, g2, total, shift);
-      shift += ceil_log2_u64(S);
+                         red_[cur * 2 + 1].as<uint32_t>(), (const uint32_t*)nullptr, n_in, S, g2, total, pl.L);
       n_in = g2;
       cur = nxt;
     }
@@ -486,10 +486,8 @@ class Engine : public IEngine {
           xyzz_dbl(t, acc);
           acc = t;
         }
-      Xyzz<F> row, cc, w, t;
-      host_load_xyzz(row, h_final_ + (size_t)k * XW);
-      host_load_xyzz(cc, h_final_ + (size_t)(kMaxWindows + k) * XW);
-      xyzz_add(w, row, cc);
+      Xyzz<F> w, t;
+      host_load_xyzz(w, h_final_ + (size_t)(kMaxWindows + k) * XW);   // W_k = C of the last level
       xyzz_add(t, acc, w);
       acc = t;
     }
@@ -584,7 +582,7 @@ class Engine : public IEngine {
     // ---- bucket reduction: level 1 from affine bucket sums, then XYZZ levels down to one entry per window
     using P = WeierPolicy<F>;
     const uint32_t S1 = first_group_size(pl);
-    const uint32_t groups = (pl.L + S1 - 1) / S1;
+    const uint32_t groups = (pl.L + 1 + S1 - 1) / S1;   // elements are weights 0..L
     if ((st = red_[0].ensure((size_t)pl.K * groups * XW * 4))) return st;
     if ((st = red_[1].ensure((size_t)pl.K * groups * XW * 4))) return st;
     {
@@ -594,7 +592,7 @@ class Engine : public IEngine {
                          refs_.as<uint32_t>(), off_.as<uint32_t>(), pl.L, S1, groups, total);
     }
     int cur = 0;
-    if ((st = reduce_levels<P>(pl, cur, groups, ceil_log2_u64(S1)))) return st;
+    if ((st = reduce_levels<P>(pl, cur, groups))) return st;
     const int ev_red_end = pl.ei;
     mark(pl);
     if ((st = fetch_window_sums<P>(pl, cur))) return st;
@@ -640,17 +638,17 @@ class Engine : public IEngine {
     const int ev_acc_end = pl.ei;
     mark(pl);
     const uint32_t S1 = first_group_size(pl);
-    const uint32_t groups = (pl.L + S1 - 1) / S1;
+    const uint32_t groups = (pl.L + 1 + S1 - 1) / S1;   // elements are weights 0..L
     if ((st = red_[0].ensure((size_t)pl.K * groups * AW * 4))) return st;
     if ((st = red_[1].ensure((size_t)pl.K * groups * AW * 4))) return st;
     {
       uint32_t total = pl.K * groups;
       hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_, red_[0].as<uint32_t>(),
                          red_[1].as<uint32_t>(), slots_.as<uint32_t>(), (const uint32_t*)nullptr,
-                         rscan_.as<uint32_t>(), pl.L, S1, groups, total, 0);
+                         rscan_.as<uint32_t>(), pl.L + 1, S1, groups, total, pl.L);
     }
     int cur = 0;
-    if ((st = reduce_levels<P>(pl, cur, groups, ceil_log2_u64(S1)))) return st;
+    if ((st = reduce_levels<P>(pl, cur, groups))) return st;
     const int ev_red_end = pl.ei;
     mark(pl);
     if ((st = fetch_window_sums<P>(pl, cur))) return st;
@@ -692,10 +690,8 @@ class Engine : public IEngine {
           te_add(t, acc, acc);
           acc = t;
         }
-      TeExt<F> row, cc, w, t;
-      host_load_te(row, h_final_ + (size_t)k * XW);
-      host_load_te(cc, h_final_ + (size_t)(kMaxWindows + k) * XW);
-      te_add(w, row, cc);
+      TeExt<F> w, t;
+      host_load_te(w, h_final_ + (size_t)(kMaxWindows + k) * XW);
       te_add(t, acc, w);
       acc = t;
     }
@@ -721,7 +717,7 @@ class Engine : public IEngine {
     constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
     // pairs per thread: as many as keep >= ~4 workgroups per CU in flight, capped at BMAX
     int B = 1;
-    while (B < BMAX && (uint64_t)pairs >= (uint64_t)T * (B * 2) * 1024) B *= 2;
+    while (B < BMAX && (uint64_t)pairs >= (uint64_t)T * (B * 2) * batch_min_wgs_) B *= 2;
     if (batch_b_override_ > 0) B = batch_b_override_ < BMAX ? batch_b_override_ : BMAX;
     dim3 grid((pairs + T * B - 1) / (T * B)), block(T);
     if constexpr (!TE) {
@@ -827,6 +823,8 @@ class Engine : public IEngine {
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
   uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 1024u;
+  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 1024u;
+  uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
   DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;

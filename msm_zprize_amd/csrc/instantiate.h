@@ -29,7 +29,9 @@
 #define MSMZ_WEIERSTRASS_FIELDS(X) MSMZ_W0(X) MSMZ_W1(X) MSMZ_W2(X)
 #define MSMZ_TE_FIELDS(X) MSMZ_T3(X)
 
-#define MSMZ_BATCH_T 256
+#ifndef MSMZ_BATCH_T
+#define MSMZ_BATCH_T 128
+#endif
 #define MSMZ_BATCH_OCC 2
 #define MSMZ_BATCH_BMAX 16
 
@@ -41,7 +43,7 @@
 
 #define MSMZ_INST_POLICY(P, PFX)                                                                                 \
   PFX template __global__ void k_reduce_next<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
-                                                const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, int);   \
+                                                const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t); \
   PFX template __global__ void k_bucket_accumulate<P>(uint32_t*, const uint32_t*, const uint32_t*,               \
                                                       const uint32_t*, const uint32_t*, uint32_t, uint32_t);
 

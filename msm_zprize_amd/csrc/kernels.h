@@ -579,6 +579,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   __shared__ int32_t tree[N * T];
   __shared__ uint32_t s_desc[BMAX * T];   // posA | kind << 28 | "B is an original point" << 31
   const uint32_t total = meta->round_pairs[r];
+  const uint32_t dbg = meta->pad;   // timing experiments only (MSMZ_DBG): 1 = no inversion, 2 = no tree, 8 = all gathers hit record 0
   const uint32_t m = 1u << r;
   const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
 
@@ -600,6 +601,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       posA = start + a;
       if (r > 0 && !(b + 1 < size)) desc |= 8u;
       PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
+      if (dbg & 8u) { op.recA = points; op.recB = points + RW; }
       Affine<F> p1, p2;
       bool infA = load_affine<F>(p1, op.recA, op.negA);
       bool infB = load_affine<F>(p2, op.recB, op.negB);
@@ -651,6 +653,8 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   }
 
   // ---------------------------------------------------------------- workgroup-wide inversion of the T products
+  Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
+  if (!(dbg & 2u)) {
   {
     Fe<F> partner, node;
 #pragma unroll
@@ -684,7 +688,8 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     Fe<F> root, inv;
 #pragma unroll
     for (int j = 0; j < N; j++) root.l[j] = tree[j * T + lvl_off];
-    bool ok = fe_inverse(inv, root);
+    bool ok = true;
+    if (dbg & 1u) inv = root; else ok = fe_inverse(inv, root);
     if (threadIdx.x == 0) {
       if (!ok) atomicOr(&meta->error, 1u);
 #pragma unroll
@@ -714,7 +719,6 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     }
     __syncthreads();
   }
-  Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
   {
     Fe<F> partner, ninv;
 #pragma unroll
@@ -723,6 +727,9 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       ninv.l[j] = tree[j * T + (threadIdx.x >> 1)];
     }
     fe_mul(run, ninv, partner);
+  }
+  } else {
+    run = prefix;
   }
 
   // ---------------------------------------------------------------- backward pass
@@ -885,10 +892,13 @@ __device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const 
   return load_affine<F>(p, slots + (size_t)start * RW, 0);
 }
 
-// Level 1.  Window k's buckets (0-based index i = l - 1 in [0, L)) are cut into groups of S; group a
-// yields   row_a = sum_b B[aS + b]   and   tri_a = sum_b b * B[aS + b]   by the running-sum trick
-// (msm-batched-affine.ts:556-559), so that   sum_i i*B_i = sum_a tri_a + S * sum_a a * row_a.
-// rows/tris: XYZZ records (4*NW words) indexed [k * groups + a].
+// Bucket reduction  W_k = sum_{l=1..L} l * B_l  (msm-batched-affine.ts:544-571) by grouped running sums.
+// Elements are indexed by their weight j = l in [0, L] (element 0 is empty), cut into groups of S = 2^s:
+//   row_a = sum_b E[aS + b],   tri_a = sum_b b * E[aS + b]          (running-sum trick, :556-559)
+//   sum_j j * E_j = sum_a tri_a + sum_a a * (S * row_a)
+// so the next level runs the same computation on the *scaled* rows S*row_a (s doublings per group) and
+// simply adds up the tri's:  C'_A = sum_b C[AS + b] + tri'_A.  After the last level (one entry per
+// window) C is W_k.  No per-level power-of-two scaling of the partial sums is needed.
 template <class F>
 __global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
                                                       const uint32_t* points, const uint32_t* refs, const uint32_t* off,
@@ -896,40 +906,36 @@ __global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* 
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t k = t / groups, a = t - k * groups;
-  uint32_t g0 = k * L + a * S;
-  Xyzz<F> run, tri;
+  Xyzz<F> run, tri, tmp;
   xyzz_set_inf(run);
   xyzz_set_inf(tri);
-  for (uint32_t b = S; b-- > 1;) {
+  for (uint32_t b = S; b-- > 0;) {
+    const uint32_t j = a * S + b;           // weight; bucket l = j
     Affine<F> p;
-    bool inf = (a * S + b >= L) ? true : load_bucket_sum<F>(p, g0 + b, slots, points, refs, off);
-    Xyzz<F> tmp;
+    bool inf = (j == 0 || j > L) ? true : load_bucket_sum<F>(p, k * L + (j - 1), slots, points, refs, off);
     xyzz_madd(tmp, run, p, inf);
     run = tmp;
-    xyzz_add(tmp, tri, run);
-    tri = tmp;
+    if (b >= 1) {
+      xyzz_add(tmp, tri, run);
+      tri = tmp;
+    }
   }
-  {
-    Affine<F> p;
-    bool inf = load_bucket_sum<F>(p, g0, slots, points, refs, off);
-    Xyzz<F> tmp;
-    xyzz_madd(tmp, run, p, inf);
+  for (uint32_t s = S; s > 1; s >>= 1) {
+    xyzz_dbl(tmp, run);
     run = tmp;
   }
   store_xyzz<F>(rows + (size_t)t * 4 * F::NW, run);
   store_xyzz<F>(tris + (size_t)t * 4 * F::NW, tri);
 }
 
-// Level >= 2 on accumulator inputs: for group A of S consecutive entries (per window, n_in entries):
-//   row'_A = sum_b row[AS+b],  tri'_A = sum_b b*row[AS+b],  C'_A = sum_b C[AS+b] + 2^shift * tri'_A
-// where 2^shift is the product of all previous group sizes.  After the last level (one entry per
-// window)  sum_i i*B_i = C  and  sum_i B_i = row.
-// With c_in == nullptr this is also the FIRST level of the msmBasic path: entry i of window k is then
-// the sum of the partial accumulators  rows_in[cscan[kL+i] .. cscan[kL+i+1])  (cscan != nullptr).
+// Level >= 2 on accumulator inputs (n_in entries per window), same recurrence.
+// With c_in == nullptr this is the FIRST level of the msmBasic path: element j of window k (j in [0, L],
+// n_in = L + 1) is then the sum of the partial accumulators rows_in[cscan[g] .. cscan[g+1]) of bucket
+// g = k*L + j - 1  (cscan != nullptr), and element 0 is empty.
 template <class P>
 __global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
                                                      const uint32_t* c_in, const uint32_t* cscan, uint32_t n_in,
-                                                     uint32_t S, uint32_t groups, uint32_t total, int shift) {
+                                                     uint32_t S, uint32_t groups, uint32_t total, uint32_t L) {
   constexpr int XW = P::ACC_WORDS;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
@@ -940,19 +946,21 @@ __global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_
   P::zero(tri);
   P::zero(cs);
   for (uint32_t b = S; b-- > 0;) {
-    if (A * S + b >= n_in) continue;
-    if (c_in != nullptr) {
+    const uint32_t e = A * S + b;
+    if (e >= n_in) continue;
+    if (cscan != nullptr) {
+      if (e >= 1) {
+        const size_t g = (size_t)k * L + (e - 1);
+        for (uint32_t q = cscan[g]; q < cscan[g + 1]; q++) {
+          P::load(p, rows_in + (size_t)q * XW);
+          P::add(tmp, run, p);
+          run = tmp;
+        }
+      }
+    } else {
       P::load(p, c_in + (base + b) * XW);
       P::add(tmp, cs, p);
       cs = tmp;
-    }
-    if (cscan != nullptr) {
-      for (uint32_t q = cscan[base + b]; q < cscan[base + b + 1]; q++) {
-        P::load(p, rows_in + (size_t)q * XW);
-        P::add(tmp, run, p);
-        run = tmp;
-      }
-    } else {
       P::load(p, rows_in + (base + b) * XW);
       P::add(tmp, run, p);
       run = tmp;
@@ -962,9 +970,9 @@ __global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_
       tri = tmp;
     }
   }
-  for (int s = 0; s < shift; s++) {
-    P::dbl(tmp, tri);
-    tri = tmp;
+  for (uint32_t s = S; s > 1; s >>= 1) {
+    P::dbl(tmp, run);
+    run = tmp;
   }
   P::add(tmp, cs, tri);
   P::store(rows_out + (size_t)t * XW, run);
