@@ -298,6 +298,7 @@ class Engine : public IEngine {
   struct Plan {
     uint32_t n, M, L, nb, nblocks;
     int c, K, b;
+    int Keff, spread;           // bucket windows incl. the top window's 2^spread sub-windows
     bool glv, timing;
     uint32_t max_bucket = 0, n_entries = 0;
     int ei = 0;                 // next event slot
@@ -324,8 +325,27 @@ class Engine : public IEngine {
     if (pl.c > 24) pl.c = 24;
     pl.K = (pl.b + 1 + pl.c - 1) / pl.c;                      // msm-batched-affine.ts:96
     pl.L = 1u << (pl.c - 1);
-    const uint64_t nb64 = (uint64_t)pl.K * pl.L;
-    if (nb64 + 1 >= (1ull << 31) || (uint64_t)pl.K * pl.M >= (1ull << 32) || pl.K > kMaxWindows) return MSMZ_ERR_ARG;
+    // significant bits of the top window's digit (from the actual largest scalar, q - 1, or the GLV bound);
+    // spread it over 2^sb sub-windows when it is sparse
+    int t_top = pl.b + 1 - (pl.K - 1) * pl.c;
+    if (!glv) {
+      const int pos = (pl.K - 1) * pl.c;
+      uint64_t top = 0;
+      for (int j = 0; j < 64 && pos + j < 256; j++)
+        top |= (uint64_t)((Fr::Q[(pos + j) >> 5] >> ((pos + j) & 31)) & 1u) << j;
+      top += 1;   // carry from the window below
+      t_top = ceil_log2_u64(top + 1);
+    }
+    pl.spread = 0;
+    if (!no_spread_ && pl.K > 1 && t_top <= pl.c - 2) {
+      pl.spread = pl.c - 1 - t_top;
+      if (pl.spread > 3) pl.spread = 3;
+      const int fbx = (pl.c - 1) < 8 ? (pl.c - 1) : 8;
+      while (pl.spread > 0 && ((pl.L >> fbx) << pl.spread) > (uint32_t)COARSE_MAX_BINS) pl.spread--;
+    }
+    pl.Keff = pl.K - 1 + (1 << pl.spread);
+    const uint64_t nb64 = (uint64_t)pl.Keff * pl.L;
+    if (nb64 + 1 >= (1ull << 31) || (uint64_t)pl.K * pl.M >= (1ull << 32) || pl.Keff > kMaxWindows) return MSMZ_ERR_ARG;
     pl.nb = (uint32_t)nb64;
     pl.nblocks = (pl.nb + SCAN_TILE - 1) / SCAN_TILE;
     pl.timing = opt.timing != 0;
@@ -352,8 +372,8 @@ class Engine : public IEngine {
     const int fb_max = 31 - idx_bits;
     const int fb = (c - 1) < fb_max ? (c - 1) : fb_max;
     const uint32_t ncb = L >> fb;
-    const uint32_t nbins = (uint32_t)K * ncb;
-    const bool sort2 = !force_atomic_sort_ && M <= (1u << 24) && ncb <= (uint32_t)COARSE_MAX_BINS &&
+    const uint32_t nbins = (uint32_t)pl.Keff * ncb;
+    const bool sort2 = !force_atomic_sort_ && M <= (1u << 24) && (ncb << pl.spread) <= (uint32_t)COARSE_MAX_BINS &&
                        (size_t)nbins * 4 <= 48 * 1024;
     const uint32_t dgrid = (n + 256 * DIGITS_ITEMS - 1) / (256 * DIGITS_ITEMS);
     if (sort2) {
@@ -365,10 +385,10 @@ class Engine : public IEngine {
       if (pl.glv) {
         if constexpr (Fr::HAS_GLV)
           hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), (size_t)nbins * 4, stream_,
-                             digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb);
+                             digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb, pl.spread);
       } else {
         hipLaunchKernelGGL((k_digits<Fr, false>), dim3(dgrid), dim3(256), (size_t)nbins * 4, stream_,
-                           digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb);
+                           digits_.as<uint32_t>(), counts_.as<uint32_t>(), d_scalars, n, c, K, fb, pl.spread);
       }
       mark(pl);  // 1
       const uint32_t bblocks = (nbins + SCAN_TILE - 1) / SCAN_TILE;
@@ -389,7 +409,7 @@ class Engine : public IEngine {
         dim3 grid(gx, K);
         hipLaunchKernelGGL((k_scatter_coarse<COARSE_MAX_BINS>), grid, dim3(COARSE_T), 0, stream_,
                            packed_.as<uint32_t>(), cursor_.as<uint32_t>(), bins_.as<uint32_t>(),
-                           digits_.as<uint32_t>(), M, fb, ncb, idx_bits, tiles);
+                           digits_.as<uint32_t>(), M, fb, ncb, idx_bits, tiles, pl.spread);
       }
       pl.ev_coarse = pl.ei;
       mark(pl);  // 3
@@ -402,10 +422,10 @@ class Engine : public IEngine {
       if (pl.glv) {
         if constexpr (Fr::HAS_GLV)
           hipLaunchKernelGGL((k_digits<Fr, true>), dim3(dgrid), dim3(256), 0, stream_, digits_.as<uint32_t>(),
-                             counts_.as<uint32_t>(), d_scalars, n, c, K, 0);
+                             counts_.as<uint32_t>(), d_scalars, n, c, K, 0, pl.spread);
       } else {
         hipLaunchKernelGGL((k_digits<Fr, false>), dim3(dgrid), dim3(256), 0, stream_, digits_.as<uint32_t>(),
-                           counts_.as<uint32_t>(), d_scalars, n, c, K, 0);
+                           counts_.as<uint32_t>(), d_scalars, n, c, K, 0, pl.spread);
       }
       mark(pl);  // 1
       hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
@@ -419,7 +439,7 @@ class Engine : public IEngine {
       {
         dim3 grid((M + 256 * 4 - 1) / (256 * 4), K);
         hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, stream_, refs_.as<uint32_t>(), cursor_.as<uint32_t>(),
-                           off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c);
+                           off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c, pl.spread);
       }
       pl.ev_coarse = pl.ei;
       mark(pl);  // 3
@@ -443,12 +463,19 @@ class Engine : public IEngine {
       uint32_t S = n_in <= 8 ? (1u << ceil_log2_u64(n_in)) : 4;
       uint32_t g2 = (n_in + S - 1) / S;
       int nxt = cur ^ 1;
-      if ((st = red_[nxt * 2].ensure((size_t)pl.K * g2 * AW * 4))) return st;
-      if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.K * g2 * AW * 4))) return st;
-      uint32_t total = pl.K * g2;
-      hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_,
-                         red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(), red_[cur * 2].as<uint32_t>(),
-                         red_[cur * 2 + 1].as<uint32_t>(), (const uint32_t*)nullptr, n_in, S, g2, total, pl.L);
+      if ((st = red_[nxt * 2].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
+      if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
+      uint32_t total = pl.Keff * g2;
+      if (S == 4 && !no_quad_) {
+        hipLaunchKernelGGL((k_reduce_quad<P>), dim3((total * 4 + 63) / 64), dim3(64), 0, stream_,
+                           red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
+                           red_[cur * 2].as<uint32_t>(), red_[cur * 2 + 1].as<uint32_t>(), n_in, g2, total);
+      } else {
+        hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_,
+                           red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
+                           red_[cur * 2].as<uint32_t>(), red_[cur * 2 + 1].as<uint32_t>(), (const uint32_t*)nullptr,
+                           n_in, S, g2, total, pl.L);
+      }
       n_in = g2;
       cur = nxt;
     }
@@ -457,7 +484,7 @@ class Engine : public IEngine {
 
   uint32_t first_group_size(const Plan& pl) const {
     uint32_t S1 = 2;
-    while ((uint64_t)pl.K * (pl.L / (S1 * 2)) >= 131072 && S1 * 2 <= pl.L && S1 < 16) S1 *= 2;
+    while ((uint64_t)pl.Keff * (pl.L / (S1 * 2)) >= 131072 && S1 * 2 <= pl.L && S1 < 16) S1 *= 2;
     if (S1 > pl.L) S1 = pl.L;
     return S1;
   }
@@ -467,8 +494,8 @@ class Engine : public IEngine {
   int fetch_window_sums(const Plan& pl, int cur) {
     constexpr int AW = P::ACC_WORDS;
     MSMZ_HIP(hipGetLastError());
-    MSMZ_HIP(hipMemcpyAsync(h_final_, red_[cur * 2].p, (size_t)pl.K * AW * 4, hipMemcpyDeviceToHost, stream_));
-    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, red_[cur * 2 + 1].p, (size_t)pl.K * AW * 4,
+    MSMZ_HIP(hipMemcpyAsync(h_final_, red_[cur * 2].p, (size_t)pl.Keff * AW * 4, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, red_[cur * 2 + 1].p, (size_t)pl.Keff * AW * 4,
                             hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipMemcpyAsync(h_meta_, meta_.p, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
@@ -479,8 +506,8 @@ class Engine : public IEngine {
   void finalize_weierstrass(const Plan& pl, uint8_t* out, int* out_inf) {
     Xyzz<F> acc;
     xyzz_set_inf(acc);
-    for (int k = pl.K - 1; k >= 0; k--) {
-      if (k != pl.K - 1)
+    for (int k = pl.Keff - 1; k >= 0; k--) {
+      if (k < pl.K - 1)   // windows K-1 .. Keff-1 are the sub-windows of the top window: same weight
         for (int j = 0; j < pl.c; j++) {
           Xyzz<F> t;
           xyzz_dbl(t, acc);
@@ -583,10 +610,10 @@ class Engine : public IEngine {
     using P = WeierPolicy<F>;
     const uint32_t S1 = first_group_size(pl);
     const uint32_t groups = (pl.L + 1 + S1 - 1) / S1;   // elements are weights 0..L
-    if ((st = red_[0].ensure((size_t)pl.K * groups * XW * 4))) return st;
-    if ((st = red_[1].ensure((size_t)pl.K * groups * XW * 4))) return st;
+    if ((st = red_[0].ensure((size_t)pl.Keff * groups * XW * 4))) return st;
+    if ((st = red_[1].ensure((size_t)pl.Keff * groups * XW * 4))) return st;
     {
-      uint32_t total = pl.K * groups;
+      uint32_t total = pl.Keff * groups;
       hipLaunchKernelGGL((k_reduce_first<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
                          red_[0].as<uint32_t>(), red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points,
                          refs_.as<uint32_t>(), off_.as<uint32_t>(), pl.L, S1, groups, total);
@@ -639,10 +666,10 @@ class Engine : public IEngine {
     mark(pl);
     const uint32_t S1 = first_group_size(pl);
     const uint32_t groups = (pl.L + 1 + S1 - 1) / S1;   // elements are weights 0..L
-    if ((st = red_[0].ensure((size_t)pl.K * groups * AW * 4))) return st;
-    if ((st = red_[1].ensure((size_t)pl.K * groups * AW * 4))) return st;
+    if ((st = red_[0].ensure((size_t)pl.Keff * groups * AW * 4))) return st;
+    if ((st = red_[1].ensure((size_t)pl.Keff * groups * AW * 4))) return st;
     {
-      uint32_t total = pl.K * groups;
+      uint32_t total = pl.Keff * groups;
       hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_, red_[0].as<uint32_t>(),
                          red_[1].as<uint32_t>(), slots_.as<uint32_t>(), (const uint32_t*)nullptr,
                          rscan_.as<uint32_t>(), pl.L + 1, S1, groups, total, pl.L);
@@ -683,8 +710,8 @@ class Engine : public IEngine {
     auto t_host0 = std::chrono::steady_clock::now();
     TeExt<F> acc;
     te_set_zero(acc);
-    for (int k = pl.K - 1; k >= 0; k--) {
-      if (k != pl.K - 1)
+    for (int k = pl.Keff - 1; k >= 0; k--) {
+      if (k < pl.K - 1)
         for (int j = 0; j < pl.c; j++) {
           TeExt<F> t;
           te_add(t, acc, acc);
@@ -825,6 +852,8 @@ class Engine : public IEngine {
   uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 1024u;
   uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 1024u;
   uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
+  bool no_quad_ = getenv("MSMZ_NO_QUAD") != nullptr;
+  bool no_spread_ = getenv("MSMZ_NO_SPREAD") != nullptr;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
   DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;

@@ -42,6 +42,8 @@
       uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, int, MsmMeta*);
 
 #define MSMZ_INST_POLICY(P, PFX)                                                                                 \
+  PFX template __global__ void k_reduce_quad<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, uint32_t, \
+                                                uint32_t, uint32_t);                                             \
   PFX template __global__ void k_reduce_next<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
                                                 const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t); \
   PFX template __global__ void k_bucket_accumulate<P>(uint32_t*, const uint32_t*, const uint32_t*,               \
@@ -56,13 +58,13 @@
 #define MSMZ_INST_REDUCE_TE(F, Fr, PFX) MSMZ_INST_POLICY(TePolicy<F>, PFX)
 
 #define MSMZ_INST_SCALAR(Fr, PFX)                                                                                 \
-  PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int); \
+  PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int, int); \
   PFX template __global__ void k_gen_scalars<Fr>(uint32_t*, uint32_t, uint64_t);
 
 #define MSMZ_INST_MISC(F, Fr, PFX)                                                                                \
   PFX template __global__ void k_points_to_mont<F>(uint32_t*, const uint32_t*, const uint8_t*, uint32_t, int);    \
   PFX template __global__ void k_points_from_mont<F>(uint32_t*, const uint32_t*, uint32_t);                       \
-  PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int); \
+  PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int, int); \
   MSMZ_INST_SCALAR(Fr, PFX)
 
 #define MSMZ_INST_MISC_TE(F, Fr, PFX)                                                              \

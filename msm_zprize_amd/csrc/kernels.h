@@ -164,19 +164,25 @@ __global__ void __launch_bounds__(256) k_points_from_mont(uint32_t* out, const u
 constexpr int DIGITS_ITEMS = 8;
 
 template <class Fr, bool GLV>
+// `spread` = sb > 0: the top window has few significant bits, so its entries are dealt over 2^sb
+// sub-windows K-1 .. K-1+2^sb-1 by the low bits of the point index (every sub-window keeps the weight
+// 2^(c(K-1))); this keeps bucket sizes balanced (the job of splitBuckets' special case for the sparse top
+// window, msm-common.ts:105-112, 146-174).
 __global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* counts, const uint32_t* scalars,
-                                                uint32_t n, int c, int K, int shift) {
+                                                uint32_t n, int c, int K, int shift, int spread) {
   extern __shared__ uint32_t s_hist[];
   const uint32_t L = 1u << (c - 1);
   const uint32_t M = GLV ? 2 * n : n;
   const uint32_t bins_per_window = L >> shift;
-  const uint32_t nbins = (uint32_t)K * bins_per_window;
+  const uint32_t nbins = (uint32_t)(K - 1 + (1 << spread)) * bins_per_window;
+  const uint32_t smask = (1u << spread) - 1u;
   if (shift) {
     for (uint32_t b = threadIdx.x; b < nbins; b += 256) s_hist[b] = 0;
     __syncthreads();
   }
-  auto tally = [&](uint32_t k, uint32_t l) {
+  auto tally = [&](uint32_t k, uint32_t l, uint32_t entry) {
     if (l == 0) return;
+    if (k == (uint32_t)(K - 1)) k += entry & smask;
     const uint32_t bin = k * bins_per_window + ((l - 1) >> shift);
     if (shift) {
       atomicAdd(&s_hist[bin], 1u);
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* coun
           // the half scalar's own sign flips every digit's sign
           uint32_t ng = (carry ^ neg[half]) & (l != 0 ? 1u : 0u);
           digits[(size_t)k * M + (size_t)half * n + i] = l | (ng << 31);
-          tally(k, l);
+          tally(k, l, half * n + i);
         }
       }
     } else {
@@ -226,7 +232,7 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* coun
           carry = 0;
         }
         digits[(size_t)k * M + i] = l | (carry << 31);
-        tally(k, l);
+        tally(k, l, i);
       }
     }
   }
@@ -340,7 +346,7 @@ static __global__ void __launch_bounds__(SCAN_T) k_scan_apply(uint32_t* out, con
 // (This is the HBM-bound "bucket scatter": algorithmic bytes = 4 B digit read + 4 B reference write
 // per entry)
 static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t* cursor, const uint32_t* off,
-                                                 const uint32_t* digits, uint32_t M, int c) {
+                                                 const uint32_t* digits, uint32_t M, int c, int spread) {
   constexpr int ITEMS = 4;
   const uint32_t L = 1u << (c - 1);
   const uint32_t k = blockIdx.y;
@@ -353,7 +359,8 @@ static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t
     uint32_t d = dk[i];
     uint32_t l = d & REF_IDX;
     if (l == 0) continue;
-    uint32_t g = k * L + (l - 1);
+    const uint32_t kw = (k + 1 == gridDim.y) ? k + (i & ((1u << spread) - 1u)) : k;
+    uint32_t g = kw * L + (l - 1);
     uint32_t pos = off[g] + atomicAdd(&cursor[g], 1u);
     refs[pos] = i | (d & REF_NEG);
   }
@@ -382,8 +389,8 @@ constexpr int COARSE_MAX_BINS = 512;                  // bins per window the LDS
 template <int NBINS_MAX>
 static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* packed_out, uint32_t* bin_cursor,
                                                                     const uint32_t* bin_base, const uint32_t* digits,
-                                                                    uint32_t M, int fb, uint32_t ncb, int idx_bits,
-                                                                    uint32_t tiles) {
+                                                                    uint32_t M, int fb, uint32_t ncb_window, int idx_bits,
+                                                                    uint32_t tiles, int spread) {
   __shared__ uint32_t s_cnt[NBINS_MAX + 1];   // entries of this tile per bin, then exclusive scan (+ total)
   __shared__ uint32_t s_gbase[NBINS_MAX];     // global address of this tile's run in each bin
   __shared__ uint32_t s_stage[COARSE_TILE];
@@ -392,6 +399,11 @@ static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* pa
   const uint32_t k = blockIdx.y;
   const uint32_t* dk = digits + (size_t)k * M;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the top window's tile is dealt over 2^spread sub-windows: (index & mask) selects the sub-window,
+  // whose bins follow each other in the global bin order
+  const bool top = (k + 1 == gridDim.y) && spread > 0;
+  const uint32_t smask = top ? (1u << spread) - 1u : 0u;
+  const uint32_t ncb = top ? ncb_window << spread : ncb_window;
 
   auto load_tile = [&](uint32_t tile, uint4* v) {
     const uint32_t tile0 = tile * COARSE_TILE;
@@ -432,7 +444,7 @@ static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* pa
         bin[e] = 0xffff;
         if (l != 0) {
           const uint32_t idx = l - 1;
-          bin[e] = (uint16_t)(idx >> fb);
+          bin[e] = (uint16_t)((i & smask) * ncb_window + (idx >> fb));
           val[e] = ((idx & ((1u << fb) - 1u)) << (idx_bits + 1)) | ((d >> 31) << idx_bits) | i;
           rank[e] = atomicAdd(&s_cnt[bin[e]], 1u);
         }
@@ -454,7 +466,7 @@ static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* pa
       const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
       if (b < ncb) {
         s_cnt[b] = ex;
-        const uint32_t gb = k * ncb + b;
+        const uint32_t gb = k * ncb_window + b;
         s_gbase[b] = my_cnt[q] ? bin_base[gb] + atomicAdd(&bin_cursor[gb], my_cnt[q]) : 0u;
         ex += my_cnt[q];
       }
@@ -977,6 +989,73 @@ __global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_
   P::add(tmp, cs, tri);
   P::store(rows_out + (size_t)t * XW, run);
   P::store(c_out + (size_t)t * XW, tmp);
+}
+
+// Same recurrence with S = 4, one group per QUAD of lanes: the 9 accumulator additions + 2 doublings of a
+// group form a dependency graph of depth 4, so four lanes finish a group in 4 sequential point
+// operations instead of 14 (the upper reduction levels are latency-bound: few groups, long chains).
+//   step 1: L0 r0+r1        L1 b = r1+r3     L2 a = r2+r3     L3 c2+c3
+//   step 2: L0 row = s01+a   L1 c0+c1         L2 2a            -
+//   step 3: L0 2 row         L1 cs = c01+c23  L2 tri = b+2a    -
+//   step 4: L0 4 row         L1 C' = cs+tri
+// Operands travel between the lanes of a quad with ds_bpermute (lane shuffles of the limbs).
+template <class P>
+__device__ __forceinline__ void quad_fetch(typename P::Acc& got, const typename P::Acc& pub, int src_lane) {
+  constexpr int NWORDS = sizeof(typename P::Acc) / 4;
+  const int32_t* in = reinterpret_cast<const int32_t*>(&pub);
+  int32_t* out = reinterpret_cast<int32_t*>(&got);
+#pragma unroll
+  for (int j = 0; j < NWORDS; j++) out[j] = __shfl(in[j], src_lane, 64);
+}
+
+template <class P>
+__global__ void __launch_bounds__(64) k_reduce_quad(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+                                                    const uint32_t* c_in, uint32_t n_in, uint32_t groups,
+                                                    uint32_t total) {
+  constexpr int XW = P::ACC_WORDS;
+  using Acc = typename P::Acc;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t grp = t >> 2, q = t & 3;
+  const bool live = grp < total;
+  const uint32_t k = live ? grp / groups : 0, A = live ? grp - k * groups : 0;
+  const uint32_t e = A * 4 + q;
+  const int lane = threadIdx.x & 63, base_lane = lane & ~3;
+  Acc r, c, v, w, got;
+  P::zero(r);
+  P::zero(c);
+  if (live && e < n_in) {
+    P::load(r, rows_in + ((size_t)k * n_in + e) * XW);
+    P::load(c, c_in + ((size_t)k * n_in + e) * XW);
+  }
+  // step 1: pub = {-, r, c, r}; src = {1, 3, 3, 2}
+  {
+    const int src[4] = {1, 3, 3, 2};
+    quad_fetch<P>(got, q == 2 ? c : r, base_lane + src[q]);
+    P::add(v, q == 3 ? c : r, got);     // L0 s01, L1 b, L2 a, L3 c23
+  }
+  // step 2: pub = {c0, -, a, -}; src = {2, 0, 2, 3}
+  {
+    const int src[4] = {2, 0, 2, 3};
+    quad_fetch<P>(got, q == 0 ? c : v, base_lane + src[q]);
+    if (q == 3) P::zero(got);
+    Acc lhs = (q == 1) ? c : v;
+    if (q == 3) P::zero(lhs);
+    P::add(w, lhs, got);                // L0 row, L1 c01, L2 2a, L3 0
+  }
+  // step 3: pub = {-, b, -, c23} (the step-1 results v); src = {0, 3, 1, 3}
+  {
+    const int src[4] = {0, 3, 1, 3};
+    quad_fetch<P>(got, q == 0 ? w : v, base_lane + src[q]);
+    P::add(r, w, got);                  // L0 2 row, L1 cs, L2 tri     (r is free now)
+  }
+  // step 4: pub = step-3 results; src = {0, 2, 2, 3}
+  {
+    const int src[4] = {0, 2, 2, 3};
+    quad_fetch<P>(got, r, base_lane + src[q]);
+    P::add(c, r, got);                  // L0 4 row, L1 C' = cs + tri
+  }
+  if (live && q == 0) P::store(rows_out + (size_t)grp * XW, c);
+  if (live && q == 1) P::store(c_out + (size_t)grp * XW, c);
 }
 
 }  // namespace msmz
