@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--glv", type=int, default=0)
     ap.add_argument("--c", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=17)
+    ap.add_argument("--cpu-log2n", type=int, default=20)
     args = ap.parse_args()
 
     import torch
@@ -71,22 +71,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from msm_zprize_amd import sharding
+
     def one_step(s, verbose=True):
         out = par.msmUnsafe(scalar_sets[s], points, n, verbose, opts)
-        res = out["result"]
-        if world > 1:
-            # exchange step: gather the per-GPU partial sums, add on the host
-            fb = curve.fe_bytes
-            rec = res["x"].to_bytes(fb, "little") + res["y"].to_bytes(fb, "little") + bytes([1 if res["isZero"] else 0]) + bytes(3)
-            t = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
-            gathered = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(gathered, t)
-            total = {"x": 0, "y": 1, "isZero": True}
-            for g in gathered:
-                b = bytes(g.cpu().numpy())
-                p = {"x": int.from_bytes(b[:fb], "little"), "y": int.from_bytes(b[fb:2 * fb], "little"), "isZero": b[2 * fb] != 0}
-                total = curve.pointAdd(total, p)
-            res = total
+        # exchange step (N > 1): gather the per-GPU partial sums over RCCL, add them on the host
+        res = sharding.combine_partials(params, out["result"], device=torch.device("cuda", local_rank))
         return out, res
 
     for s in range(args.warmup):
@@ -132,8 +122,8 @@ def main():
                                    f"{'GLV' if args.glv else 'no GLV'}, affine buckets (batched-affine), msmUnsafe",
                        "log2n_per_gpu": log2n, "c": c, "K": K, "glv": bool(args.glv),
                        "point_adds_per_msm": total_entries / args.steps / world, "sharding": f"input-split x{world}"},
-            "roofline": {"kernel": "k_scatter", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"kernel": "k_scatter_coarse", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": scatter_traffic(),
                          "bytes_per_launch": scatter_bytes, "avg_launch_ms": scatter_ms},
             "valu_roofline": {"kernel": "k_batch_add (all rounds)", "bound": "int32 VALU (v_mad_i64_i32)",
                               "achieved": pairs * 6 / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
@@ -149,6 +139,17 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scatter_traffic():
+    """HBM bytes per launch of k_scatter_coarse from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE, separate passes; see profiles/README.md for the corrections applied)."""
+    path = os.path.join(ROOT, "profiles", "r01_scatter_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(params, log2n):

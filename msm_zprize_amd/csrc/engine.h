@@ -87,9 +87,9 @@ static inline int ceil_log2_u64(uint64_t x) {
 // is latency-bound, so c stays well below log2(N).
 static inline int default_window(uint64_t n_points) {
   int lg = ceil_log2_u64(n_points < 2 ? 2 : n_points);
-  int c = lg - 4;
+  int c = lg - 3;
   if (c < 3) c = 3;
-  if (c > 16) c = 16;
+  if (c > 17) c = 17;   // 2^16 buckets per window: the largest the two-level LDS sort handles in one coarse pass
   return c;
 }
 
@@ -340,7 +340,10 @@ class Engine : public IEngine {
     if (!no_spread_ && pl.K > 1 && t_top <= pl.c - 2) {
       pl.spread = pl.c - 1 - t_top;
       if (pl.spread > 3) pl.spread = 3;
-      const int fbx = (pl.c - 1) < 8 ? (pl.c - 1) : 8;
+      const int ib = ceil_log2_u64(pl.M < 2 ? 2 : pl.M);
+      int fbm = 31 - ib > FINE_MAX_BITS ? FINE_MAX_BITS : 31 - ib;
+      if (fb_cap_ > 0 && fbm > fb_cap_) fbm = fb_cap_;
+      const int fbx = (pl.c - 1) < fbm ? (pl.c - 1) : fbm;
       while (pl.spread > 0 && ((pl.L >> fbx) << pl.spread) > (uint32_t)COARSE_MAX_BINS) pl.spread--;
     }
     pl.Keff = pl.K - 1 + (1 << pl.spread);
@@ -368,8 +371,12 @@ class Engine : public IEngine {
     MSMZ_HIP(hipMemsetAsync(d_meta, 0, sizeof(MsmMeta), stream_));
     if (dbg_) MSMZ_HIP(hipMemcpyAsync(&d_meta->pad, &dbg_, 4, hipMemcpyHostToDevice, stream_));
     // two-level LDS-staged sort when the packed (fine | negate | index) word fits; else per-entry atomics
-    const int idx_bits = M <= (1u << 23) ? 23 : 24;
-    const int fb_max = 31 - idx_bits;
+    // packed word = fine bucket bits | negate | index: the narrower the index, the more fine bits fit, the
+    // fewer (and longer) coarse runs the scatter writes
+    const int idx_bits = ceil_log2_u64(M < 2 ? 2 : M);
+    int fb_max = 31 - idx_bits;
+    if (fb_max > FINE_MAX_BITS) fb_max = FINE_MAX_BITS;
+    if (fb_cap_ > 0 && fb_max > fb_cap_) fb_max = fb_cap_;
     const int fb = (c - 1) < fb_max ? (c - 1) : fb_max;
     const uint32_t ncb = L >> fb;
     const uint32_t nbins = (uint32_t)pl.Keff * ncb;
@@ -483,6 +490,7 @@ class Engine : public IEngine {
   }
 
   uint32_t first_group_size(const Plan& pl) const {
+    if (s1_override_ > 0) return s1_override_ < pl.L ? s1_override_ : pl.L;
     uint32_t S1 = 2;
     while ((uint64_t)pl.Keff * (pl.L / (S1 * 2)) >= 131072 && S1 * 2 <= pl.L && S1 < 16) S1 *= 2;
     if (S1 > pl.L) S1 = pl.L;
@@ -852,6 +860,8 @@ class Engine : public IEngine {
   uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 1024u;
   uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 1024u;
   uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
+  int fb_cap_ = getenv("MSMZ_FB") ? atoi(getenv("MSMZ_FB")) : 0;
+  uint32_t s1_override_ = getenv("MSMZ_S1") ? (uint32_t)atoi(getenv("MSMZ_S1")) : 0u;
   bool no_quad_ = getenv("MSMZ_NO_QUAD") != nullptr;
   bool no_spread_ = getenv("MSMZ_NO_SPREAD") != nullptr;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;

@@ -380,7 +380,7 @@ static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t
 //                          by coarse bin, writes (fine | negate | index) words (4 B) in contiguous runs
 //   k_sort_fine            one workgroup per coarse bin: LDS histogram of its <= 256 buckets -> bucket
 //                          offsets `off`, then places every reference at its final sorted position
-constexpr int SORT_FB_MAX = 8;     // fine bits when the index needs <= 23 bits; 31 - idx_bits in general
+constexpr int SORT_FB_MAX = 8;     // (historic default) fine bits = min(c-1, 31 - idx_bits, FINE_MAX_BITS)
 constexpr int COARSE_T = 256;
 constexpr int COARSE_ITEMS = 32;
 constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // 8192 entries per workgroup
@@ -492,27 +492,40 @@ static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* pa
 
 // One workgroup per coarse bin.  Phase A: histogram of the bin's buckets in LDS -> off[] for those buckets
 // (+ running maximum bucket size); phase B: every entry goes to its final position.
+constexpr int FINE_MAX_BITS = 11;
+
 static __global__ void __launch_bounds__(256) k_sort_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
                                                           const uint32_t* packed, const uint32_t* bin_base, int fb,
                                                           uint32_t n_bins, int idx_bits) {
-  __shared__ uint32_t s_cnt[1 << SORT_FB_MAX];
-  __shared__ uint32_t s_cur[1 << SORT_FB_MAX];
+  __shared__ uint32_t s_cnt[1 << FINE_MAX_BITS];
+  __shared__ uint32_t s_cur[1 << FINE_MAX_BITS];
   __shared__ uint32_t s_wave[4];
   const uint32_t bin = blockIdx.x;
   const uint32_t nfine = 1u << fb;
+  const uint32_t per = (nfine + 255) / 256;        // consecutive buckets per thread
   const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
-  if (threadIdx.x < nfine) s_cnt[threadIdx.x] = 0;
+  for (uint32_t f = threadIdx.x; f < nfine; f += 256) s_cnt[f] = 0;
   __syncthreads();
   for (uint32_t p = begin + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
   __syncthreads();
-  const uint32_t c = threadIdx.x < nfine ? s_cnt[threadIdx.x] : 0;
-  uint32_t total;
-  const uint32_t ex = block_exclusive_scan(c, &total, s_wave);
-  if (threadIdx.x < nfine) {
-    s_cur[threadIdx.x] = begin + ex;
-    off[(size_t)bin * nfine + threadIdx.x] = begin + ex;
-    if (c > 1) atomicMax(max_bucket, c);
+  uint32_t mine = 0, mx = 0;
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t f = threadIdx.x * per + j;
+    const uint32_t c = f < nfine ? s_cnt[f] : 0;
+    mine += c;
+    mx = c > mx ? c : mx;
   }
+  uint32_t total;
+  uint32_t ex = begin + block_exclusive_scan(mine, &total, s_wave);
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t f = threadIdx.x * per + j;
+    if (f < nfine) {
+      s_cur[f] = ex;
+      off[(size_t)bin * nfine + f] = ex;
+      ex += s_cnt[f];
+    }
+  }
+  if (mx > 1) atomicMax(max_bucket, mx);
   if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
   __syncthreads();
   for (uint32_t p = begin + threadIdx.x; p < end; p += 256) {
@@ -649,11 +662,12 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
 #pragma unroll
         for (int q = 0; q < NW / 4; q++) d4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
         if (r == 0) {
-          // round 0: the slot is fresh; park x1 next to z so the backward pass needs no second gather of A
-          fe_store<F>(w, p1.x);
+          // round 0: the slot is fresh; park x1 (its words as they came from memory) next to z so the
+          // backward pass needs no second gather of A
+          const uint4* a4 = reinterpret_cast<const uint4*>(op.recA);
           uint4* x4 = reinterpret_cast<uint4*>(slots + (size_t)posA * RW);
 #pragma unroll
-          for (int q = 0; q < NW / 4; q++) x4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+          for (int q = 0; q < NW / 4; q++) x4[q] = a4[q];
         }
         Fe<F> np;
         fe_mul(np, prefix, d);
