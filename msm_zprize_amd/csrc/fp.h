@@ -421,6 +421,11 @@ MSMZ_HD bool fe_inverse(Fe<F>& r, const Fe<F>& x) {
   constexpr int ITERS = (2 * F::BITS + W - 1) / W + 1;
 #pragma unroll 1
   for (int it = 0; it < ITERS; it++) {
+    // a == 0: converged (further iterations would be the identity: f0 = 1, g1 = 2^W)
+    int32_t anyA = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) anyA |= a.l[j];
+    if (anyA == 0) break;
     // ---- approximations: low W bits + the top bits at a common alignment
     int h = 0;   // highest limb where a or b is non-zero
 #pragma unroll
