@@ -321,6 +321,16 @@ class Engine : public IEngine {
     pl.M = glv ? 2 * pl.n : pl.n;
     pl.b = glv ? Fr::GLV_BITS - 1 : Fr::BITS;                 // scalar bit length
     pl.c = opt.c > 0 ? opt.c : default_window(pl.M);
+    if (opt.c <= 0) {
+      // avoid a nearly empty top window (all its entries would share a few buckets): step c down until the
+      // top window keeps at least c - 4 significant bits (the rest is handled by sub-window spreading)
+      for (int tries = 0; tries < 3 && pl.c > 4; tries++) {
+        const int K0 = (pl.b + 1 + pl.c - 1) / pl.c;
+        const int top_bits = pl.b + 1 - (K0 - 1) * pl.c;
+        if (K0 == 1 || top_bits >= pl.c - 4) break;
+        pl.c--;
+      }
+    }
     if (pl.c < 2) pl.c = 2;
     if (pl.c > 24) pl.c = 24;
     pl.K = (pl.b + 1 + pl.c - 1) / pl.c;                      // msm-batched-affine.ts:96
@@ -420,8 +430,17 @@ class Engine : public IEngine {
       }
       pl.ev_coarse = pl.ei;
       mark(pl);  // 3
-      hipLaunchKernelGGL(k_sort_fine, dim3(nbins), dim3(256), 0, stream_, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                         &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins, idx_bits);
+      {
+        const size_t lds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+          MSMZ_HIP(hipFuncSetAttribute((const void*)k_sort_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(k_sort_fine, dim3(nbins), dim3(FINE_T), lds, stream_, refs_.as<uint32_t>(),
+                           off_.as<uint32_t>(), &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb,
+                           nbins, idx_bits);
+      }
     } else {
       MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nb + 1) * 4, stream_));
       MSMZ_HIP(hipMemsetAsync(cursor_.p, 0, (size_t)nb * 4, stream_));

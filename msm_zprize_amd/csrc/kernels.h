@@ -491,47 +491,72 @@ static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* pa
 }
 
 // One workgroup per coarse bin.  Phase A: histogram of the bin's buckets in LDS -> off[] for those buckets
-// (+ running maximum bucket size); phase B: every entry goes to its final position.
+// (+ running maximum bucket size).  Phase B: every reference goes to its final sorted position; when the
+// whole bin fits the LDS staging buffer (the normal case) the positions are filled in LDS and the bin is
+// written out as one contiguous, coalesced stream -- scattered 4-byte stores cost ~8x write amplification
+// (profiles/r01_pmc_write_summary.txt) -- otherwise straight to memory.
 constexpr int FINE_MAX_BITS = 11;
+constexpr int FINE_T = 1024;
+constexpr int FINE_STAGE = 38400;   // entries staged in LDS: 150 KB + 8 KB of counters < 160 KB
 
-static __global__ void __launch_bounds__(256) k_sort_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
-                                                          const uint32_t* packed, const uint32_t* bin_base, int fb,
-                                                          uint32_t n_bins, int idx_bits) {
-  __shared__ uint32_t s_cnt[1 << FINE_MAX_BITS];
-  __shared__ uint32_t s_cur[1 << FINE_MAX_BITS];
-  __shared__ uint32_t s_wave[4];
+static __global__ void __launch_bounds__(FINE_T) k_sort_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
+                                                             const uint32_t* packed, const uint32_t* bin_base, int fb,
+                                                             uint32_t n_bins, int idx_bits) {
+  extern __shared__ uint32_t s_dyn[];
+  uint32_t* s_cnt = s_dyn;                                  // [1 << FINE_MAX_BITS] counts, then running cursors
+  uint32_t* s_stage = s_dyn + (1 << FINE_MAX_BITS);          // [FINE_STAGE]
+  __shared__ uint32_t s_wave[FINE_T / 64];
   const uint32_t bin = blockIdx.x;
   const uint32_t nfine = 1u << fb;
-  const uint32_t per = (nfine + 255) / 256;        // consecutive buckets per thread
+  const uint32_t per = (nfine + FINE_T - 1) / FINE_T;        // consecutive buckets per thread
   const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
-  for (uint32_t f = threadIdx.x; f < nfine; f += 256) s_cnt[f] = 0;
+  const bool staged = (end - begin) <= (uint32_t)FINE_STAGE;
+  for (uint32_t f = threadIdx.x; f < nfine; f += FINE_T) s_cnt[f] = 0;
   __syncthreads();
-  for (uint32_t p = begin + threadIdx.x; p < end; p += 256) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
+  for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
   __syncthreads();
-  uint32_t mine = 0, mx = 0;
+  uint32_t mine = 0, mx = 0, cnts[2] = {0, 0};
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t f = threadIdx.x * per + j;
     const uint32_t c = f < nfine ? s_cnt[f] : 0;
+    cnts[j & 1] = c;
     mine += c;
     mx = c > mx ? c : mx;
   }
-  uint32_t total;
-  uint32_t ex = begin + block_exclusive_scan(mine, &total, s_wave);
+  // block-wide exclusive scan of `mine` over FINE_T threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w2 = 0; w2 < wave; w2++) wbase += s_wave[w2];
+  uint32_t ex = wbase + x - mine;                            // relative to the bin start
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t f = threadIdx.x * per + j;
     if (f < nfine) {
-      s_cur[f] = ex;
-      off[(size_t)bin * nfine + f] = ex;
-      ex += s_cnt[f];
+      s_cnt[f] = ex;                                         // becomes the running cursor of bucket f
+      off[(size_t)bin * nfine + f] = begin + ex;
+      ex += cnts[j & 1];
     }
   }
   if (mx > 1) atomicMax(max_bucket, mx);
   if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
   __syncthreads();
-  for (uint32_t p = begin + threadIdx.x; p < end; p += 256) {
+  const uint32_t imask = (1u << idx_bits) - 1u;
+  for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) {
     const uint32_t v = packed[p];
-    const uint32_t pos = atomicAdd(&s_cur[v >> (idx_bits + 1)], 1u);
-    refs[pos] = (v & ((1u << idx_bits) - 1u)) | (((v >> idx_bits) & 1u) << 31);
+    const uint32_t pos = atomicAdd(&s_cnt[v >> (idx_bits + 1)], 1u);
+    const uint32_t ref = (v & imask) | (((v >> idx_bits) & 1u) << 31);
+    if (staged) s_stage[pos] = ref; else refs[begin + pos] = ref;
+  }
+  if (staged) {
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < end - begin; p += FINE_T) refs[begin + p] = s_stage[p];
   }
 }
 
