@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--glv", type=int, default=0)
     ap.add_argument("--c", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: ranks share GPU 0)")
     ap.add_argument("--cpu-log2n", type=int, default=20)
     args = ap.parse_args()
 
@@ -45,10 +46,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the MSM has no CPU path)")
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0          # all ranks share the one GPU; the exchange step runs over gloo on CPU tensors
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import msm_zprize_amd as m
     from msm_zprize_amd.curves import bls12377Params as params
@@ -76,7 +83,7 @@ def main():
     def one_step(s, verbose=True):
         out = par.msmUnsafe(scalar_sets[s], points, n, verbose, opts)
         # exchange step (N > 1): gather the per-GPU partial sums over RCCL, add them on the host
-        res = sharding.combine_partials(params, out["result"], device=torch.device("cuda", local_rank))
+        res = sharding.combine_partials(params, out["result"], device=None if rehearsal else torch.device("cuda", local_rank))
         return out, res
 
     for s in range(args.warmup):
@@ -89,8 +96,9 @@ def main():
         stats.append(out["stats"])
     barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    entries = torch.tensor([float(sum(int(st.n_entries) for st in stats))], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if rehearsal else "cuda"
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    entries = torch.tensor([float(sum(int(st.n_entries) for st in stats))], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(entries, op=dist.ReduceOp.SUM)
