@@ -39,13 +39,19 @@ struct MsmMeta {               // small device-resident block of run-time totals
 };
 
 // ------------------------------------------------------------------------------------------------ loads
-template <class F>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// NT = non-temporal access.  Measured (round 1): streaming the tree rounds' slot records past the caches makes
+// k_batch_add 1.7x SLOWER (round 0: 1.9 -> 3.9 ms) -- the backward pass re-reads what the forward pass parked
+// (z, x1) and lives off L2 / Infinity Cache hits -- so SLOT_NT stays false.
+constexpr bool SLOT_NT = false;
+template <class F, bool NT = false>
 __device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src) {
   // records are 16-byte aligned: 2*NW words = 96 B / 64 B
-  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
 #pragma unroll
   for (int i = 0; i < (2 * F::NW) / 4; i++) {
-    uint4 v = s4[i];
+    u32x4 v = NT ? __builtin_nontemporal_load(s4 + i) : s4[i];
     dst[4 * i] = v.x;
     dst[4 * i + 1] = v.y;
     dst[4 * i + 2] = v.z;
@@ -53,18 +59,21 @@ __device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src) {
   }
 }
 
-template <class F>
+template <class F, bool NT = false>
 __device__ __forceinline__ void store_words(uint32_t* dst, const uint32_t* src) {
-  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  u32x4* d4 = reinterpret_cast<u32x4*>(dst);
 #pragma unroll
-  for (int i = 0; i < (2 * F::NW) / 4; i++) d4[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+  for (int i = 0; i < (2 * F::NW) / 4; i++) {
+    u32x4 v = {src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
+    if (NT) __builtin_nontemporal_store(v, d4 + i); else d4[i] = v;
+  }
 }
 
 // load an affine point record; returns true if it is the point at infinity
-template <class F>
+template <class F, bool NT = false>
 __device__ __forceinline__ bool load_affine(Affine<F>& p, const uint32_t* rec, uint32_t negate) {
   uint32_t w[2 * F::NW];
-  load_words<F>(w, rec);
+  load_words<F, NT>(w, rec);
   uint32_t o = 0;
 #pragma unroll
   for (int i = 0; i < 2 * F::NW; i++) o |= w[i];
@@ -75,7 +84,7 @@ __device__ __forceinline__ bool load_affine(Affine<F>& p, const uint32_t* rec, u
   return o == 0;
 }
 
-template <class F>
+template <class F, bool NT = false>
 __device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, bool inf) {
   uint32_t w[2 * F::NW];
   if (inf) {
@@ -86,7 +95,7 @@ __device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, 
     fe_store<F>(w + F::NW, p.y);
     // a finite point can never serialize to the all-zero record: x = y = 0 is not on the curve
   }
-  store_words<F>(rec, w);
+  store_words<F, NT>(rec, w);
 }
 
 template <class F>
@@ -653,8 +662,10 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
       if (dbg & 8u) { op.recA = points; op.recB = points + RW; }
       Affine<F> p1, p2;
-      bool infA = load_affine<F>(p1, op.recA, op.negA);
-      bool infB = load_affine<F>(p2, op.recB, op.negB);
+      // operands that live in `slots` are read once: stream them past the caches; gathers stay cached
+      bool infA = (r > 0) ? load_affine<F, SLOT_NT>(p1, op.recA, op.negA) : load_affine<F>(p1, op.recA, op.negA);
+      bool infB = (r > 0 && !(desc & 8u)) ? load_affine<F, SLOT_NT>(p2, op.recB, op.negB)
+                                          : load_affine<F>(p2, op.recB, op.negB);
       Fe<F> d, num;
       fe_sub(d, p2.x, p1.x);
       fe_sub(num, p2.y, p1.y);
@@ -683,16 +694,21 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
         fe_mul(z, prefix, num);
         uint32_t w[NW];
         fe_store_mulout<F>(w, z);
-        uint4* d4 = reinterpret_cast<uint4*>(slots + (size_t)posA * RW + NW);
+        u32x4* d4 = reinterpret_cast<u32x4*>(slots + (size_t)posA * RW + NW);
 #pragma unroll
-        for (int q = 0; q < NW / 4; q++) d4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        for (int q = 0; q < NW / 4; q++) {
+          u32x4 v = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+          if (SLOT_NT) __builtin_nontemporal_store(v, d4 + q); else d4[q] = v;
+        }
         if (r == 0) {
           // round 0: the slot is fresh; park x1 (its words as they came from memory) next to z so the
           // backward pass needs no second gather of A
-          const uint4* a4 = reinterpret_cast<const uint4*>(op.recA);
-          uint4* x4 = reinterpret_cast<uint4*>(slots + (size_t)posA * RW);
+          const u32x4* a4 = reinterpret_cast<const u32x4*>(op.recA);
+          u32x4* x4 = reinterpret_cast<u32x4*>(slots + (size_t)posA * RW);
 #pragma unroll
-          for (int q = 0; q < NW / 4; q++) x4[q] = a4[q];
+          for (int q = 0; q < NW / 4; q++) {
+            if (SLOT_NT) __builtin_nontemporal_store(a4[q], x4 + q); else x4[q] = a4[q];
+          }
         }
         Fe<F> np;
         fe_mul(np, prefix, d);
@@ -795,11 +811,11 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
     if (kind == PK_ADD || kind == PK_DBL) {
       Affine<F> p2;
-      load_affine<F>(p2, op.recB, op.negB);
+      if (r > 0 && !(desc & 8u)) load_affine<F, SLOT_NT>(p2, op.recB, op.negB); else load_affine<F>(p2, op.recB, op.negB);
       Fe<F> x1, z, mm, ms, d, t;
       {
         uint32_t w[RW];
-        load_words<F>(w, out);            // [x1 | z]  (x1 parked there in round 0, in place otherwise)
+        load_words<F, SLOT_NT>(w, out);      // [x1 | z]  (x1 parked there in round 0, in place otherwise)
         fe_unpack<F>(x1, w);
         fe_unpack<F>(z, w + NW);
       }
@@ -819,7 +835,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       fe_carry(t);
       fe_mul(ms, mm, t);
       fe_sub(res.y, ms, p2.y);            // y3 = m (x2 - x3) - y2
-      store_affine<F>(out, res, false);
+      store_affine<F, SLOT_NT>(out, res, false);
     } else if (kind == PK_TAKE_B) {
       Affine<F> p2;
       load_affine<F>(p2, op.recB, op.negB);
