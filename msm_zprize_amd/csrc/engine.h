@@ -616,6 +616,13 @@ class Engine : public IEngine {
       MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
       MSMZ_HIP(hipStreamSynchronize(stream_));
       memcpy(h_round_pairs_, h_meta_->round_pairs, sizeof(h_round_pairs_));
+      // result array of round r starts at record base[r] of `slots`
+      uint32_t base = 0;
+      for (int r = 0; r < 32; r++) {
+        h_round_base_[r] = base;
+        base += h_round_pairs_[r];
+      }
+      MSMZ_HIP(hipMemcpyAsync(d_meta->round_base, h_round_base_, sizeof(h_round_base_), hipMemcpyHostToDevice, stream_));
     }
     const int ev_plan1 = pl.ei;
     mark(pl);
@@ -626,8 +633,7 @@ class Engine : public IEngine {
       const uint32_t pairs = h_round_pairs_[r];
       n_pairs += pairs;
       if (pairs == 0) continue;
-      const uint32_t* rs = rscan_.as<uint32_t>() + (size_t)r * ((size_t)nb + 1);
-      launch_batch_add(pairs, opt.safe != 0, d_points, rs, nb, r, d_meta);
+      launch_batch_add(pairs, opt.safe != 0, d_points, rscan_.as<uint32_t>(), nb, r, d_meta);
       mark(pl);
     }
     const int ev_acc_end = pl.ei;
@@ -643,7 +649,8 @@ class Engine : public IEngine {
       uint32_t total = pl.Keff * groups;
       hipLaunchKernelGGL((k_reduce_first<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
                          red_[0].as<uint32_t>(), red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points,
-                         refs_.as<uint32_t>(), off_.as<uint32_t>(), pl.L, S1, groups, total);
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), pl.L, S1, groups, total, rscan_.as<uint32_t>(), nb,
+                         d_meta);
     }
     int cur = 0;
     if ((st = reduce_levels<P>(pl, cur, groups))) return st;
@@ -887,6 +894,7 @@ class Engine : public IEngine {
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
   DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
+  uint32_t h_round_base_[32] = {};
   int basic_ev_[4] = {};
   MsmMeta* h_meta_ = nullptr;
   uint32_t* h_final_ = nullptr;

@@ -36,6 +36,7 @@ struct MsmMeta {               // small device-resident block of run-time totals
   uint32_t error;              // bit 0: zero denominator hit in the unsafe batch add
   uint32_t pad;
   uint32_t round_pairs[32];    // number of pairs in tree round r
+  uint32_t round_base[32];     // first record of round r's result array inside `slots` (prefix sum of round_pairs)
 };
 
 // ------------------------------------------------------------------------------------------------ loads
@@ -572,74 +573,76 @@ static __global__ void __launch_bounds__(FINE_T) k_sort_fine(uint32_t* refs, uin
 // ------------------------------------------------------------------------------------------------ batch add
 // Round r (m = 2^r) of the in-bucket pair tree: inside each bucket (positions relative to its start)
 // element j*2m + m is added into element j*2m, for every j with j*2m + m < size -- exactly the
-// reference's schedule (msm-batched-affine.ts:232-247).  Sums live in `slots`, one record per sorted
-// position, written in place from round 0 on; round 0 gathers the original points through `refs`.
+// reference's schedule (msm-batched-affine.ts:232-247).
+//
+// Storage: the reference adds in place in its sorted point array.  Here every round writes a COMPACT
+// result array R_r inside `slots` (record base[r] + t for pair t of the round; pairs are numbered bucket by
+// bucket through rscan_r), so a workgroup's stores are one contiguous stream and round r+1 reads its two
+// operands from adjacent records of R_r.  The value of relative position `pos` of bucket g before round
+// r is therefore found at
+//     R_rr[rscan_rr[g] + pos / 2^(rr+1)],   rr = min(r-1, floor(log2(size-pos-1)))     (size-pos >= 2)
+//     the original point refs[start+pos]                                               (size-pos == 1 or r == 0)
+// (rr = the last round in which `pos` had a partner).  Round 0 gathers the original points through `refs`.
 //
 // Batch inversion (Montgomery's trick) on two levels:
 //   * each thread walks B pairs like batchAddUnsafeNew (curve-affine.ts:463-522): forward pass keeps a
-//     running product of the denominators and parks  z_i = numerator_i * prod_{j<i} d_j  in the output
-//     slot's y field; backward pass turns z_i into the slope with the running inverse;
+//     running product of the denominators and parks  [x1 | z_i = numerator_i * prod_{j<i} d_j]  in the pair's
+//     output record; backward pass turns z_i into the slope with the running inverse;
 //   * the T per-thread products of a workgroup are inverted together: product tree in LDS, ONE field
 //     inversion (wave 0, every lane on the same value -> no divergence), down-sweep.
 // 6 field products per addition + (3 T + inversion) per workgroup of T*B additions.
-// Slope/sum formulas use P2 (y3 = m (x2 - x3) - y2, wasm/curve.ts:63-84 addAffinePacked) because y1's
-// slot is where z_i was parked.
+// Slope/sum formulas use P2 (y3 = m (x2 - x3) - y2, wasm/curve.ts:63-84 addAffinePacked).
 //
 // SAFE handles infinity operands, equal points (doubling, denominator 2y) and opposite points
 // (result infinity) like batchAddNew (curve-affine.ts:376-458); the unsafe variant assumes distinct
 // x like batchAddUnsafeNew and raises meta->error if a zero denominator poisons a batch.
 constexpr int BATCH_BMAX = 16;
 enum { PK_NONE = 0, PK_ADD = 1, PK_DBL = 2, PK_TAKE_A = 3, PK_TAKE_B = 4, PK_INF = 5 };
+constexpr uint32_t LOC_ORIG = 0x40000000u;   // location word: bit 30 = original point (bit 31 = negate), else slot record
 
-template <class F>
-struct PairOperands {
-  const uint32_t* recA;
-  const uint32_t* recB;
-  uint32_t negA, negB;
-};
-
-template <class F>
-__device__ __forceinline__ PairOperands<F> pair_operands(uint32_t posA, uint32_t desc, uint32_t m, int r,
-                                                         const uint32_t* slots, const uint32_t* points,
-                                                         const uint32_t* refs) {
-  constexpr int RW = 2 * F::NW;
-  PairOperands<F> o;
-  const uint32_t posB = posA + m;
-  if (r == 0) {
-    uint32_t ra = refs[posA], rb = refs[posB];
-    o.recA = points + (size_t)(ra & REF_IDX) * RW;
-    o.negA = ra >> 31;
-    o.recB = points + (size_t)(rb & REF_IDX) * RW;
-    o.negB = rb >> 31;
-  } else {
-    o.recA = slots + (size_t)posA * RW;
-    o.negA = 0;
-    if (desc & 8u) {   // B was never paired before: still the original point
-      uint32_t rb = refs[posB];
-      o.recB = points + (size_t)(rb & REF_IDX) * RW;
-      o.negB = rb >> 31;
-    } else {
-      o.recB = slots + (size_t)posB * RW;
-      o.negB = 0;
-    }
+// location word of the element at relative position `pos` of bucket g (see above)
+__device__ __forceinline__ uint32_t element_location(uint32_t g, uint32_t start, uint32_t size, uint32_t pos, int r,
+                                                     const uint32_t* refs, const uint32_t* rscan_all, uint32_t nb,
+                                                     const MsmMeta* meta) {
+  const uint32_t rem = size - pos;
+  if (r == 0 || rem == 1) {
+    const uint32_t rf = refs[start + pos];
+    return (rf & REF_IDX) | (rf & REF_NEG) | LOC_ORIG;
   }
-  return o;
+  int rr = 31 - __builtin_clz(rem - 1);
+  if (rr > r - 1) rr = r - 1;
+  return meta->round_base[rr] + rscan_all[(size_t)rr * ((size_t)nb + 1) + g] + (pos >> (rr + 1));
+}
+
+template <class F>
+__device__ __forceinline__ const uint32_t* location_record(uint32_t loc, const uint32_t* slots, const uint32_t* points,
+                                                           uint32_t& neg) {
+  constexpr int RW = 2 * F::NW;
+  if (loc & LOC_ORIG) {
+    neg = loc >> 31;
+    return points + (size_t)(loc & 0x3fffffffu) * RW;
+  }
+  neg = 0;
+  return slots + (size_t)loc * RW;
 }
 
 template <class F, int T, bool SAFE, int OCC, int BMAX>
 __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
-                                                 const uint32_t* off, const uint32_t* rscan, uint32_t nb, int r, int B,
-                                                 MsmMeta* meta) {
+                                                      const uint32_t* off, const uint32_t* rscan_all, uint32_t nb, int r,
+                                                      int B, MsmMeta* meta) {
   constexpr int N = F::N;
   constexpr int NW = F::NW;
   constexpr int RW = 2 * NW;
   // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
   // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
   __shared__ int32_t tree[N * T];
-  __shared__ uint32_t s_desc[BMAX * T];   // posA | kind << 28 | "B is an original point" << 31
+  __shared__ uint32_t s_loc[BMAX * T];    // location word of operand B (of operand A for PK_TAKE_A)
+  __shared__ uint8_t s_kind[BMAX * T];
   const uint32_t total = meta->round_pairs[r];
-  const uint32_t dbg = meta->pad;   // timing experiments only (MSMZ_DBG): 1 = no inversion, 2 = no tree, 8 = all gathers hit record 0
+  const uint32_t out_base = meta->round_base[r];
+  const uint32_t dbg = meta->pad;   // timing experiments only (MSMZ_DBG): 1 = no inversion, 2 = no tree
   const uint32_t m = 1u << r;
+  const uint32_t* rscan = rscan_all + (size_t)r * ((size_t)nb + 1);
   const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
 
   Fe<F> prefix;
@@ -648,33 +651,35 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
 #pragma unroll 1
   for (int i = 0; i < B; i++) {
     const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
-    uint32_t kind = PK_NONE, posA = 0, desc = 0;
+    uint32_t kind = PK_NONE, loc_keep = 0;
     if (t < total) {
       uint32_t lo = 0, hi = nb;   // invariant rscan[lo] <= t < rscan[hi]
       while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
         if (rscan[mid] <= t) lo = mid; else hi = mid;
       }
-      const uint32_t start = off[lo], size = off[lo + 1] - start;
-      const uint32_t a = (t - rscan[lo]) * 2 * m, b = a + m;
-      posA = start + a;
-      if (r > 0 && !(b + 1 < size)) desc |= 8u;
-      PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
-      if (dbg & 8u) { op.recA = points; op.recB = points + RW; }
+      const uint32_t g = lo;
+      const uint32_t start = off[g], size = off[g + 1] - start;
+      const uint32_t a = (t - rscan[g]) * 2 * m, b = a + m;
+      const uint32_t locA = element_location(g, start, size, a, r, refs, rscan_all, nb, meta);
+      const uint32_t locB = element_location(g, start, size, b, r, refs, rscan_all, nb, meta);
+      uint32_t negA, negB;
+      const uint32_t* recA = location_record<F>(locA, slots, points, negA);
+      const uint32_t* recB = location_record<F>(locB, slots, points, negB);
       Affine<F> p1, p2;
-      // operands that live in `slots` are read once: stream them past the caches; gathers stay cached
-      bool infA = (r > 0) ? load_affine<F, SLOT_NT>(p1, op.recA, op.negA) : load_affine<F>(p1, op.recA, op.negA);
-      bool infB = (r > 0 && !(desc & 8u)) ? load_affine<F, SLOT_NT>(p2, op.recB, op.negB)
-                                          : load_affine<F>(p2, op.recB, op.negB);
+      bool infA = load_affine<F>(p1, recA, negA);
+      bool infB = load_affine<F>(p2, recB, negB);
       Fe<F> d, num;
       fe_sub(d, p2.x, p1.x);
       fe_sub(num, p2.y, p1.y);
       kind = PK_ADD;
+      loc_keep = locB;
       if (SAFE) {
         if (infA) {
           kind = infB ? PK_INF : PK_TAKE_B;
         } else if (infB) {
           kind = PK_TAKE_A;
+          loc_keep = locA;
         } else if (fe_is_zero(d)) {
           if (fe_is_zero(num) && !fe_is_zero(p1.y)) {
             kind = PK_DBL;
@@ -690,33 +695,28 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
         }
       }
       if (kind == PK_ADD || kind == PK_DBL) {
+        // park [x1 | z] in the pair's output record: x1 as the words it came with, z = prefix * numerator
         Fe<F> z;
         fe_mul(z, prefix, num);
         uint32_t w[NW];
         fe_store_mulout<F>(w, z);
-        u32x4* d4 = reinterpret_cast<u32x4*>(slots + (size_t)posA * RW + NW);
+        uint32_t* out = slots + (size_t)(out_base + t) * RW;
+        const u32x4* a4 = reinterpret_cast<const u32x4*>(recA);
+        u32x4* o4 = reinterpret_cast<u32x4*>(out);
+#pragma unroll
+        for (int q = 0; q < NW / 4; q++) o4[q] = a4[q];
 #pragma unroll
         for (int q = 0; q < NW / 4; q++) {
           u32x4 v = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
-          if (SLOT_NT) __builtin_nontemporal_store(v, d4 + q); else d4[q] = v;
-        }
-        if (r == 0) {
-          // round 0: the slot is fresh; park x1 (its words as they came from memory) next to z so the
-          // backward pass needs no second gather of A
-          const u32x4* a4 = reinterpret_cast<const u32x4*>(op.recA);
-          u32x4* x4 = reinterpret_cast<u32x4*>(slots + (size_t)posA * RW);
-#pragma unroll
-          for (int q = 0; q < NW / 4; q++) {
-            if (SLOT_NT) __builtin_nontemporal_store(a4[q], x4 + q); else x4[q] = a4[q];
-          }
+          o4[NW / 4 + q] = v;
         }
         Fe<F> np;
         fe_mul(np, prefix, d);
         prefix = np;
       }
-      desc |= kind;
     }
-    s_desc[i * T + threadIdx.x] = posA | (desc << 28);
+    s_loc[i * T + threadIdx.x] = loc_keep;
+    s_kind[i * T + threadIdx.x] = (uint8_t)kind;
   }
 
   // ---------------------------------------------------------------- workgroup-wide inversion of the T products
@@ -802,20 +802,19 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   // ---------------------------------------------------------------- backward pass
 #pragma unroll 1
   for (int i = B - 1; i >= 0; i--) {
-    const uint32_t packed = s_desc[i * T + threadIdx.x];
-    const uint32_t desc = packed >> 28;
-    const uint32_t kind = desc & 7u;
+    const uint32_t kind = s_kind[i * T + threadIdx.x];
     if (kind == PK_NONE) continue;
-    const uint32_t posA = packed & 0x0fffffffu;
-    uint32_t* out = slots + (size_t)posA * RW;
-    PairOperands<F> op = pair_operands<F>(posA, desc, m, r, slots, points, refs);
+    const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
+    uint32_t* out = slots + (size_t)(out_base + t) * RW;
+    uint32_t neg;
+    const uint32_t* rec = location_record<F>(s_loc[i * T + threadIdx.x], slots, points, neg);
     if (kind == PK_ADD || kind == PK_DBL) {
       Affine<F> p2;
-      if (r > 0 && !(desc & 8u)) load_affine<F, SLOT_NT>(p2, op.recB, op.negB); else load_affine<F>(p2, op.recB, op.negB);
-      Fe<F> x1, z, mm, ms, d, t;
+      load_affine<F>(p2, rec, neg);
+      Fe<F> x1, z, mm, ms, d, tt;
       {
         uint32_t w[RW];
-        load_words<F, SLOT_NT>(w, out);      // [x1 | z]  (x1 parked there in round 0, in place otherwise)
+        load_words<F>(w, out);            // [x1 | z] parked by the forward pass
         fe_unpack<F>(x1, w);
         fe_unpack<F>(z, w + NW);
       }
@@ -825,27 +824,21 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
         fe_add(d, p2.y, p2.y);
       }
       fe_mul(mm, z, run);                 // slope
-      fe_mul(t, run, d);
-      run = t;
+      fe_mul(tt, run, d);
+      run = tt;
       fe_sqr(ms, mm);
       Affine<F> res;
-      fe_sub(t, ms, x1);
-      fe_sub(res.x, t, p2.x);             // x3 = m^2 - x1 - x2
-      fe_sub(t, p2.x, res.x);
-      fe_carry(t);
-      fe_mul(ms, mm, t);
+      fe_sub(tt, ms, x1);
+      fe_sub(res.x, tt, p2.x);            // x3 = m^2 - x1 - x2
+      fe_sub(tt, p2.x, res.x);
+      fe_carry(tt);
+      fe_mul(ms, mm, tt);
       fe_sub(res.y, ms, p2.y);            // y3 = m (x2 - x3) - y2
-      store_affine<F, SLOT_NT>(out, res, false);
-    } else if (kind == PK_TAKE_B) {
-      Affine<F> p2;
-      load_affine<F>(p2, op.recB, op.negB);
-      store_affine<F>(out, p2, false);
-    } else if (kind == PK_TAKE_A) {
-      if (r == 0) {
-        Affine<F> p1;
-        load_affine<F>(p1, op.recA, op.negA);
-        store_affine<F>(out, p1, false);
-      }                                   // r > 0: A already sits in the output slot
+      store_affine<F>(out, res, false);
+    } else if (kind == PK_TAKE_A || kind == PK_TAKE_B) {
+      Affine<F> p;
+      load_affine<F>(p, rec, neg);
+      store_affine<F>(out, p, false);
     } else {                              // PK_INF
       Affine<F> dummy;
       store_affine<F>(out, dummy, true);
@@ -945,10 +938,11 @@ __global__ void __launch_bounds__(128) k_bucket_accumulate(uint32_t* partial, co
 
 // ------------------------------------------------------------------------------------------------ reduce
 // Bucket sum of global bucket g after all tree rounds: empty -> infinity; one element -> the original
-// point; otherwise slot[off[g]].
+// point; otherwise the result of the last round in which position 0 had a partner.
 template <class F>
 __device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const uint32_t* slots, const uint32_t* points,
-                                                const uint32_t* refs, const uint32_t* off) {
+                                                const uint32_t* refs, const uint32_t* off, const uint32_t* rscan_all,
+                                                uint32_t nb, const MsmMeta* meta) {
   constexpr int RW = 2 * F::NW;
   uint32_t start = off[g], size = off[g + 1] - start;
   if (size == 0) return true;
@@ -956,7 +950,9 @@ __device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const 
     uint32_t rf = refs[start];
     return load_affine<F>(p, points + (size_t)(rf & REF_IDX) * RW, rf >> 31);
   }
-  return load_affine<F>(p, slots + (size_t)start * RW, 0);
+  const int rr = 31 - __builtin_clz(size - 1);
+  const uint32_t rec = meta->round_base[rr] + rscan_all[(size_t)rr * ((size_t)nb + 1) + g];
+  return load_affine<F>(p, slots + (size_t)rec * RW, 0);
 }
 
 // Bucket reduction  W_k = sum_{l=1..L} l * B_l  (msm-batched-affine.ts:544-571) by grouped running sums.
@@ -969,7 +965,8 @@ __device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const 
 template <class F>
 __global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
                                                       const uint32_t* points, const uint32_t* refs, const uint32_t* off,
-                                                      uint32_t L, uint32_t S, uint32_t groups, uint32_t total) {
+                                                      uint32_t L, uint32_t S, uint32_t groups, uint32_t total,
+                                                      const uint32_t* rscan_all, uint32_t nb, const MsmMeta* meta) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t k = t / groups, a = t - k * groups;
@@ -979,7 +976,8 @@ __global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* 
   for (uint32_t b = S; b-- > 0;) {
     const uint32_t j = a * S + b;           // weight; bucket l = j
     Affine<F> p;
-    bool inf = (j == 0 || j > L) ? true : load_bucket_sum<F>(p, k * L + (j - 1), slots, points, refs, off);
+    bool inf = (j == 0 || j > L) ? true
+                                  : load_bucket_sum<F>(p, k * L + (j - 1), slots, points, refs, off, rscan_all, nb, meta);
     xyzz_madd(tmp, run, p, inf);
     run = tmp;
     if (b >= 1) {
