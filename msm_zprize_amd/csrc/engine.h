@@ -119,7 +119,7 @@ class Engine : public IEngine {
   ~Engine() override {
     (void)hipSetDevice(device_);
     for (auto& kv : handles_) (void)hipFree(kv.second.dev);
-    for (DevBuf* b : {&packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+    for (DevBuf* b : {&wgfirst_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
                       &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
       b->release();
     if (h_meta_) (void)hipHostFree(h_meta_);
@@ -486,7 +486,7 @@ class Engine : public IEngine {
     constexpr int AW = P::ACC_WORDS;
     int st;
     while (n_in > 1) {
-      uint32_t S = n_in <= 8 ? (1u << ceil_log2_u64(n_in)) : 4;
+      uint32_t S = no_quad_ ? (n_in <= 8 ? (1u << ceil_log2_u64(n_in)) : 4) : 4;   // quads handle short tails too
       uint32_t g2 = (n_in + S - 1) / S;
       int nxt = cur ^ 1;
       if ((st = red_[nxt * 2].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
@@ -511,6 +511,9 @@ class Engine : public IEngine {
   uint32_t first_group_size(const Plan& pl) const {
     if (s1_override_ > 0) return s1_override_ < pl.L ? s1_override_ : pl.L;
     uint32_t S1 = 2;
+    // L / S1 a power of 4 saves one reduction level
+    if (pl.L >= 4 && (ceil_log2_u64(pl.L) & 1) == 0) S1 = 4;
+    return S1 < pl.L ? S1 : pl.L;
     while ((uint64_t)pl.Keff * (pl.L / (S1 * 2)) >= 131072 && S1 * 2 <= pl.L && S1 < 16) S1 *= 2;
     if (S1 > pl.L) S1 = pl.L;
     return S1;
@@ -572,6 +575,10 @@ class Engine : public IEngine {
     log->stage_ms[MSMZ_ST_ACCUMULATE] = elapsed(ev_plan1, ev_acc_end);
     log->stage_ms[MSMZ_ST_REDUCE] = elapsed(ev_acc_end, ev_red_end);
     int prev = ev_plan1, rr = 0;
+    if (log_fused_) {   // all rounds ran in one launch: its time is reported as round 0
+      log->batch_add_ms[0] = elapsed(ev_plan1, round_ev0);
+      return;
+    }
     for (int r = 0; r < R && r < 32; r++) {
       if (h_round_pairs_[r] == 0) continue;
       int e = round_ev0 + rr;
@@ -629,12 +636,37 @@ class Engine : public IEngine {
     uint64_t n_pairs = 0;
     const uint32_t* d_points = (const uint32_t*)pts.dev;
     const int round_ev0 = pl.ei;
-    for (int r = 0; r < R; r++) {
-      const uint32_t pairs = h_round_pairs_[r];
-      n_pairs += pairs;
-      if (pairs == 0) continue;
-      launch_batch_add(pairs, opt.safe != 0, d_points, rscan_.as<uint32_t>(), nb, r, d_meta);
+    for (int r = 0; r < R; r++) n_pairs += h_round_pairs_[r];
+    // Balanced buckets (the normal case): all rounds in ONE launch, each workgroup owning a range of buckets.
+    // Very large buckets (adversarial inputs, e.g. many equal scalars): one launch per round, pairs split evenly.
+    const bool fused = !no_fused_ && R > 0 && pl.max_bucket <= fused_max_bucket_;
+    log_fused_ = fused;
+    if (fused) {
+      constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
+      const uint32_t ppw = (uint32_t)T * fused_b_;
+      const uint32_t n_wgs = (h_round_pairs_[0] + ppw - 1) / ppw;
+      if ((st = wgfirst_.ensure(((size_t)n_wgs + 2) * 4))) return st;
+      hipLaunchKernelGGL(k_wg_first_bucket, dim3((n_wgs + 1 + 255) / 256), dim3(256), 0, stream_,
+                         wgfirst_.as<uint32_t>(), rscan_.as<uint32_t>(), nb, ppw, n_wgs);
+      if constexpr (!TE) {
+        if (opt.safe != 0) {
+          hipLaunchKernelGGL((k_batch_add_fused<F, T, true, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
+                             slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
+                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>());
+        } else {
+          hipLaunchKernelGGL((k_batch_add_fused<F, T, false, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
+                             slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
+                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>());
+        }
+      }
       mark(pl);
+    } else {
+      for (int r = 0; r < R; r++) {
+        const uint32_t pairs = h_round_pairs_[r];
+        if (pairs == 0) continue;
+        launch_batch_add(pairs, opt.safe != 0, d_points, rscan_.as<uint32_t>(), nb, r, d_meta);
+        mark(pl);
+      }
     }
     const int ev_acc_end = pl.ei;
     mark(pl);
@@ -642,7 +674,7 @@ class Engine : public IEngine {
     // ---- bucket reduction: level 1 from affine bucket sums, then XYZZ levels down to one entry per window
     using P = WeierPolicy<F>;
     const uint32_t S1 = first_group_size(pl);
-    const uint32_t groups = (pl.L + 1 + S1 - 1) / S1;   // elements are weights 0..L
+    const uint32_t groups = (pl.L + S1 - 1) / S1;   // elements are weights 0..L-1 (weight L folded into L/2)
     if ((st = red_[0].ensure((size_t)pl.Keff * groups * XW * 4))) return st;
     if ((st = red_[1].ensure((size_t)pl.Keff * groups * XW * 4))) return st;
     {
@@ -699,14 +731,14 @@ class Engine : public IEngine {
     const int ev_acc_end = pl.ei;
     mark(pl);
     const uint32_t S1 = first_group_size(pl);
-    const uint32_t groups = (pl.L + 1 + S1 - 1) / S1;   // elements are weights 0..L
+    const uint32_t groups = (pl.L + S1 - 1) / S1;   // elements are weights 0..L-1 (weight L folded into L/2)
     if ((st = red_[0].ensure((size_t)pl.Keff * groups * AW * 4))) return st;
     if ((st = red_[1].ensure((size_t)pl.Keff * groups * AW * 4))) return st;
     {
       uint32_t total = pl.Keff * groups;
       hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_, red_[0].as<uint32_t>(),
                          red_[1].as<uint32_t>(), slots_.as<uint32_t>(), (const uint32_t*)nullptr,
-                         rscan_.as<uint32_t>(), pl.L + 1, S1, groups, total, pl.L);
+                         rscan_.as<uint32_t>(), pl.L, S1, groups, total, pl.L);
     }
     int cur = 0;
     if ((st = reduce_levels<P>(pl, cur, groups))) return st;
@@ -730,6 +762,7 @@ class Engine : public IEngine {
     finalize_weierstrass(pl, out, out_inf);
     float host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     memset(h_round_pairs_, 0, sizeof(h_round_pairs_));
+    log_fused_ = false;
     fill_log(log, pl, 0, pl.n_entries, basic_ev_[0], basic_ev_[1], basic_ev_[2], basic_ev_[3], 0, host_ms);
     return MSMZ_OK;
   }
@@ -762,6 +795,7 @@ class Engine : public IEngine {
     *out_inf = 0;
     float host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     memset(h_round_pairs_, 0, sizeof(h_round_pairs_));
+    log_fused_ = false;
     fill_log(log, pl, 0, pl.n_entries, basic_ev_[0], basic_ev_[1], basic_ev_[2], basic_ev_[3], 0, host_ms);
     return MSMZ_OK;
   }
@@ -883,16 +917,22 @@ class Engine : public IEngine {
   hipEvent_t ev_[kMaxEvents] = {};
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
-  uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 1024u;
-  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 1024u;
+  uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 2048u;
+  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 512u;
   uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
   int fb_cap_ = getenv("MSMZ_FB") ? atoi(getenv("MSMZ_FB")) : 0;
   uint32_t s1_override_ = getenv("MSMZ_S1") ? (uint32_t)atoi(getenv("MSMZ_S1")) : 0u;
+  // single-launch variant of the tree rounds: measured 1.8x slower than one launch per round (late rounds leave
+  // most of each workgroup idle while it still pays a serial inversion per round) -> opt-in only
+  bool no_fused_ = getenv("MSMZ_FUSED") == nullptr;
+  uint32_t fused_max_bucket_ = getenv("MSMZ_FUSED_MAXB") ? (uint32_t)atoi(getenv("MSMZ_FUSED_MAXB")) : 2048u;
+  uint32_t fused_b_ = getenv("MSMZ_FUSED_B") ? (uint32_t)atoi(getenv("MSMZ_FUSED_B")) : 16u;
   bool no_quad_ = getenv("MSMZ_NO_QUAD") != nullptr;
   bool no_spread_ = getenv("MSMZ_NO_SPREAD") != nullptr;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
-  DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  DevBuf wgfirst_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  bool log_fused_ = false;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};
   int basic_ev_[4] = {};

@@ -35,7 +35,14 @@
 #define MSMZ_BATCH_OCC 2
 #define MSMZ_BATCH_BMAX 16
 
+#define MSMZ_INST_BATCH_FUSED(F, SAFE, PFX)                                                                       \
+  PFX template __global__ void k_batch_add_fused<F, MSMZ_BATCH_T, SAFE, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(         \
+      uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, MsmMeta*,      \
+      const uint32_t*);
+
 #define MSMZ_INST_BATCH(F, Fr, PFX)                                                                               \
+  MSMZ_INST_BATCH_FUSED(F, true, PFX)                                                                             \
+  MSMZ_INST_BATCH_FUSED(F, false, PFX)                                                                            \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, true, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(              \
       uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, int, MsmMeta*); \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, false, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(             \

@@ -392,7 +392,10 @@ static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t
 //                          offsets `off`, then places every reference at its final sorted position
 constexpr int SORT_FB_MAX = 8;     // (historic default) fine bits = min(c-1, 31 - idx_bits, FINE_MAX_BITS)
 constexpr int COARSE_T = 256;
-constexpr int COARSE_ITEMS = 32;
+#ifndef MSMZ_COARSE_ITEMS
+#define MSMZ_COARSE_ITEMS 32
+#endif
+constexpr int COARSE_ITEMS = MSMZ_COARSE_ITEMS;
 constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // 8192 entries per workgroup
 constexpr int COARSE_MAX_BINS = 512;                  // bins per window the LDS staging supports
 
@@ -626,24 +629,20 @@ __device__ __forceinline__ const uint32_t* location_record(uint32_t loc, const u
   return slots + (size_t)loc * RW;
 }
 
-template <class F, int T, bool SAFE, int OCC, int BMAX>
-__global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
-                                                      const uint32_t* off, const uint32_t* rscan_all, uint32_t nb, int r,
-                                                      int B, MsmMeta* meta) {
+// One batch: pairs [block_base, min(block_base + T*B, total)) of round r, B per thread; buckets of these pairs lie
+// in [g_min, g_max] (search window).  LDS: tree[N*T], s_loc[BMAX*T], s_kind[BMAX*T] owned by the caller.
+template <class F, int T, bool SAFE, int BMAX>
+__device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
+                                                const uint32_t* off, const uint32_t* rscan_all, uint32_t nb, int r, int B,
+                                                MsmMeta* meta, uint32_t block_base, uint32_t total, uint32_t g_min,
+                                                uint32_t g_max, int32_t* tree, uint32_t* s_loc, uint8_t* s_kind) {
   constexpr int N = F::N;
   constexpr int NW = F::NW;
   constexpr int RW = 2 * NW;
-  // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
-  // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
-  __shared__ int32_t tree[N * T];
-  __shared__ uint32_t s_loc[BMAX * T];    // location word of operand B (of operand A for PK_TAKE_A)
-  __shared__ uint8_t s_kind[BMAX * T];
-  const uint32_t total = meta->round_pairs[r];
   const uint32_t out_base = meta->round_base[r];
   const uint32_t dbg = meta->pad;   // timing experiments only (MSMZ_DBG): 1 = no inversion, 2 = no tree
   const uint32_t m = 1u << r;
   const uint32_t* rscan = rscan_all + (size_t)r * ((size_t)nb + 1);
-  const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
 
   Fe<F> prefix;
   fe_set_const<F>(prefix, F::ONE);
@@ -653,7 +652,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
     uint32_t kind = PK_NONE, loc_keep = 0;
     if (t < total) {
-      uint32_t lo = 0, hi = nb;   // invariant rscan[lo] <= t < rscan[hi]
+      uint32_t lo = g_min, hi = g_max + 1;   // invariant rscan[lo] <= t < rscan[hi]
       while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
         if (rscan[mid] <= t) lo = mid; else hi = mid;
@@ -846,6 +845,69 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   }
 }
 
+// One launch per tree round (any bucket sizes): workgroup w handles pairs [w*T*B, (w+1)*T*B) of round r.
+template <class F, int T, bool SAFE, int OCC, int BMAX>
+__global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
+                                                      const uint32_t* off, const uint32_t* rscan_all, uint32_t nb, int r,
+                                                      int B, MsmMeta* meta) {
+  // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
+  // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
+  __shared__ int32_t tree[F::N * T];
+  __shared__ uint32_t s_loc[BMAX * T];    // location word of operand B (of operand A for PK_TAKE_A)
+  __shared__ uint8_t s_kind[BMAX * T];
+  batch_add_chunk<F, T, SAFE, BMAX>(slots, points, refs, off, rscan_all, nb, r, B, meta,
+                                    blockIdx.x * (uint32_t)(T * B), meta->round_pairs[r], 0u, nb - 1, tree, s_loc, s_kind);
+}
+
+// ALL tree rounds in one launch: the pair tree of a bucket only depends on that bucket, so workgroup w owns the
+// buckets [wg_first[w], wg_first[w+1]) (cut so that every workgroup gets ~pairs_per_wg round-0 pairs) and runs
+// rounds 0 .. R-1 on them back to back.  No grid-wide barrier between rounds: while one workgroup sits in its
+// serial inversion the others on the CU compute, and a round's results are re-read by the same workgroup.
+// Between rounds the workgroup's stores must be visible to its own loads: barrier + agent-scope fence
+// (the CU's vector L1 may hold the [x1 | z] record that the result overwrote).
+static __global__ void __launch_bounds__(256) k_wg_first_bucket(uint32_t* wg_first, const uint32_t* rscan0, uint32_t nb,
+                                                                uint32_t pairs_per_wg, uint32_t n_wgs) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > n_wgs) return;
+  uint32_t g = nb;
+  if (w < n_wgs) {
+    const uint64_t target = (uint64_t)w * pairs_per_wg;   // smallest g with rscan0[g] >= target
+    uint32_t lo = 0, hi = nb;
+    while (lo < hi) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (rscan0[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    g = lo;
+  }
+  wg_first[w] = g;
+}
+
+template <class F, int T, bool SAFE, int OCC, int BMAX>
+__global__ void __launch_bounds__(T, OCC) k_batch_add_fused(uint32_t* slots, const uint32_t* points,
+                                                            const uint32_t* refs, const uint32_t* off,
+                                                            const uint32_t* rscan_all, uint32_t nb, int R,
+                                                            MsmMeta* meta, const uint32_t* wg_first) {
+  __shared__ int32_t tree[F::N * T];
+  __shared__ uint32_t s_loc[BMAX * T];
+  __shared__ uint8_t s_kind[BMAX * T];
+  const uint32_t g_lo = wg_first[blockIdx.x], g_hi = wg_first[blockIdx.x + 1];   // buckets [g_lo, g_hi)
+  if (g_lo >= g_hi) return;
+  for (int r = 0; r < R; r++) {
+    const uint32_t* rscan = rscan_all + (size_t)r * ((size_t)nb + 1);
+    const uint32_t p_lo = rscan[g_lo], p_hi = rscan[g_hi];
+    for (uint32_t base = p_lo; base < p_hi; base += (uint32_t)(T * BMAX)) {
+      const uint32_t left = p_hi - base;
+      int B = (int)((left + T - 1) / T);
+      if (B > BMAX) B = BMAX;
+      batch_add_chunk<F, T, SAFE, BMAX>(slots, points, refs, off, rscan_all, nb, r, B, meta, base, p_hi, g_lo, g_hi - 1,
+                                        tree, s_loc, s_kind);
+      __syncthreads();   // s_loc / s_kind / tree are reused by the next batch
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ group policies
 // The bucket accumulation of the msmBasic path and the bucket reduction are written once over a small
 // "group policy": accumulator type + how to fold an input point record into it.
@@ -956,14 +1018,15 @@ __device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const 
 }
 
 // Bucket reduction  W_k = sum_{l=1..L} l * B_l  (msm-batched-affine.ts:544-571) by grouped running sums.
-// Elements are indexed by their weight j = l in [0, L] (element 0 is empty), cut into groups of S = 2^s:
+// Elements are indexed by their weight j = l in [0, L) (element 0 is empty; the one bucket of weight L is
+// folded into element L/2 twice), cut into groups of S = 2^s:
 //   row_a = sum_b E[aS + b],   tri_a = sum_b b * E[aS + b]          (running-sum trick, :556-559)
 //   sum_j j * E_j = sum_a tri_a + sum_a a * (S * row_a)
 // so the next level runs the same computation on the *scaled* rows S*row_a (s doublings per group) and
 // simply adds up the tri's:  C'_A = sum_b C[AS + b] + tri'_A.  After the last level (one entry per
 // window) C is W_k.  No per-level power-of-two scaling of the partial sums is needed.
 template <class F>
-__global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
+__global__ void __launch_bounds__(128, 2) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
                                                       const uint32_t* points, const uint32_t* refs, const uint32_t* off,
                                                       uint32_t L, uint32_t S, uint32_t groups, uint32_t total,
                                                       const uint32_t* rscan_all, uint32_t nb, const MsmMeta* meta) {
@@ -974,12 +1037,20 @@ __global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* 
   xyzz_set_inf(run);
   xyzz_set_inf(tri);
   for (uint32_t b = S; b-- > 0;) {
-    const uint32_t j = a * S + b;           // weight; bucket l = j
+    const uint32_t j = a * S + b;           // weight; bucket l = j, j in [0, L)
     Affine<F> p;
-    bool inf = (j == 0 || j > L) ? true
-                                  : load_bucket_sum<F>(p, k * L + (j - 1), slots, points, refs, off, rscan_all, nb, meta);
+    bool inf = (j == 0 || j >= L) ? true
+                                   : load_bucket_sum<F>(p, k * L + (j - 1), slots, points, refs, off, rscan_all, nb, meta);
     xyzz_madd(tmp, run, p, inf);
     run = tmp;
+    if (j == L / 2 && L >= 2) {
+      // the single bucket of weight L is folded in as 2 * (L/2): keeps the element count a power of two
+      bool inf2 = load_bucket_sum<F>(p, k * L + (L - 1), slots, points, refs, off, rscan_all, nb, meta);
+      xyzz_madd(tmp, run, p, inf2);
+      run = tmp;
+      xyzz_madd(tmp, run, p, inf2);
+      run = tmp;
+    }
     if (b >= 1) {
       xyzz_add(tmp, tri, run);
       tri = tmp;
@@ -996,7 +1067,7 @@ __global__ void __launch_bounds__(128) k_reduce_first(uint32_t* rows, uint32_t* 
 // Level >= 2 on accumulator inputs (n_in entries per window), same recurrence.
 // With c_in == nullptr this is the FIRST level of the msmBasic path: element j of window k (j in [0, L],
 // n_in = L + 1) is then the sum of the partial accumulators rows_in[cscan[g] .. cscan[g+1]) of bucket
-// g = k*L + j - 1  (cscan != nullptr), and element 0 is empty.
+// g = k*L + j - 1  (cscan != nullptr), element 0 is empty and bucket L is folded into element L/2 twice (n_in = L).
 template <class P>
 __global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
                                                      const uint32_t* c_in, const uint32_t* cscan, uint32_t n_in,
@@ -1021,6 +1092,15 @@ __global__ void __launch_bounds__(128) k_reduce_next(uint32_t* rows_out, uint32_
           P::add(tmp, run, p);
           run = tmp;
         }
+      }
+      if (e == L / 2 && L >= 2) {   // weight-L bucket folded in as 2 * (L/2)
+        const size_t g = (size_t)k * L + (L - 1);
+        for (int twice = 0; twice < 2; twice++)
+          for (uint32_t q = cscan[g]; q < cscan[g + 1]; q++) {
+            P::load(p, rows_in + (size_t)q * XW);
+            P::add(tmp, run, p);
+            run = tmp;
+          }
       }
     } else {
       P::load(p, c_in + (base + b) * XW);
@@ -1062,7 +1142,7 @@ __device__ __forceinline__ void quad_fetch(typename P::Acc& got, const typename 
 }
 
 template <class P>
-__global__ void __launch_bounds__(64) k_reduce_quad(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+__global__ void __launch_bounds__(64, 2) k_reduce_quad(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
                                                     const uint32_t* c_in, uint32_t n_in, uint32_t groups,
                                                     uint32_t total) {
   constexpr int XW = P::ACC_WORDS;
