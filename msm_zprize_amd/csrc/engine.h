@@ -492,7 +492,12 @@ class Engine : public IEngine {
       if ((st = red_[nxt * 2].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
       if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
       uint32_t total = pl.Keff * g2;
-      if (S == 4 && !no_quad_) {
+      if (S == 4 && !no_quad_ && total <= quad16_max_groups_) {
+        // small level: latency-bound, one DPP quad per addition
+        hipLaunchKernelGGL((k_reduce_quad16<P>), dim3((total * 16 + 63) / 64), dim3(64), 0, stream_,
+                           red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
+                           red_[cur * 2].as<uint32_t>(), red_[cur * 2 + 1].as<uint32_t>(), n_in, g2, total);
+      } else if (S == 4 && !no_quad_) {
         hipLaunchKernelGGL((k_reduce_quad<P>), dim3((total * 4 + 63) / 64), dim3(64), 0, stream_,
                            red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
                            red_[cur * 2].as<uint32_t>(), red_[cur * 2 + 1].as<uint32_t>(), n_in, g2, total);
@@ -928,6 +933,7 @@ class Engine : public IEngine {
   uint32_t fused_max_bucket_ = getenv("MSMZ_FUSED_MAXB") ? (uint32_t)atoi(getenv("MSMZ_FUSED_MAXB")) : 2048u;
   uint32_t fused_b_ = getenv("MSMZ_FUSED_B") ? (uint32_t)atoi(getenv("MSMZ_FUSED_B")) : 16u;
   bool no_quad_ = getenv("MSMZ_NO_QUAD") != nullptr;
+  uint32_t quad16_max_groups_ = getenv("MSMZ_QUAD16") ? (uint32_t)atoi(getenv("MSMZ_QUAD16")) : 8192u;   // levels with at most this many groups use k_reduce_quad16
   bool no_spread_ = getenv("MSMZ_NO_SPREAD") != nullptr;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;

@@ -51,6 +51,8 @@
 #define MSMZ_INST_POLICY(P, PFX)                                                                                 \
   PFX template __global__ void k_reduce_quad<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, uint32_t, \
                                                 uint32_t, uint32_t);                                             \
+  PFX template __global__ void k_reduce_quad16<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,        \
+                                                  uint32_t, uint32_t, uint32_t);                                 \
   PFX template __global__ void k_reduce_next<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
                                                 const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t); \
   PFX template __global__ void k_bucket_accumulate<P>(uint32_t*, const uint32_t*, const uint32_t*,               \

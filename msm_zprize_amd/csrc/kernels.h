@@ -636,6 +636,7 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
                                                 const uint32_t* off, const uint32_t* rscan_all, uint32_t nb, int r, int B,
                                                 MsmMeta* meta, uint32_t block_base, uint32_t total, uint32_t g_min,
                                                 uint32_t g_max, int32_t* tree, uint32_t* s_loc, uint8_t* s_kind) {
+  __shared__ uint32_t s_span[2];
   constexpr int N = F::N;
   constexpr int NW = F::NW;
   constexpr int RW = 2 * NW;
@@ -646,18 +647,37 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
 
   Fe<F> prefix;
   fe_set_const<F>(prefix, F::ONE);
+  // Buckets spanned by this batch: two lanes search the whole window [g_min, g_max] for the first and the last
+  // pair, every pair then searches only that span (and only upwards of the thread's previous pair).
+  if (threadIdx.x < 2) {
+    uint32_t tt = block_base;
+    if (threadIdx.x == 1) {
+      tt = block_base + (uint32_t)(T * B) - 1;
+      if (tt >= total) tt = total - 1;
+    }
+    uint32_t lo = g_min, hi = g_max + 1;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (rscan[mid] <= tt) lo = mid; else hi = mid;
+    }
+    s_span[threadIdx.x] = lo;
+  }
+  __syncthreads();
+  uint32_t g_prev = s_span[0];
+  const uint32_t g_last = s_span[1];
   // ---------------------------------------------------------------- forward pass
 #pragma unroll 1
   for (int i = 0; i < B; i++) {
     const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
     uint32_t kind = PK_NONE, loc_keep = 0;
     if (t < total) {
-      uint32_t lo = g_min, hi = g_max + 1;   // invariant rscan[lo] <= t < rscan[hi]
+      uint32_t lo = g_prev, hi = g_last + 1;   // invariant rscan[lo] <= t < rscan[hi]
       while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
         if (rscan[mid] <= t) lo = mid; else hi = mid;
       }
       const uint32_t g = lo;
+      g_prev = g;
       const uint32_t start = off[g], size = off[g + 1] - start;
       const uint32_t a = (t - rscan[g]) * 2 * m, b = a + m;
       const uint32_t locA = element_location(g, start, size, a, r, refs, rscan_all, nb, meta);
@@ -908,6 +928,117 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add_fused(uint32_t* slots, con
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 4-lane point addition
+// The upper reduction levels are latency-bound (a handful of waves, each alone on its SIMD, running 14
+// dependent field products per XYZZ addition).  There one addition is spread over the 4 lanes of a DPP
+// quad instead: every lane holds the same operands, each computes one of the (up to) four independent
+// products of a dependency level, and the products are exchanged with quad_perm DPP moves (no LDS) --
+// depth 4 products instead of 14 (twisted Edwards: 3 instead of 9).
+template <class F>
+__device__ __forceinline__ void fe_sel4(Fe<F>& r, int s, const Fe<F>& a0, const Fe<F>& a1, const Fe<F>& a2,
+                                        const Fe<F>& a3) {
+#pragma unroll
+  for (int j = 0; j < F::N; j++) {
+    int32_t lo = (s & 1) ? a1.l[j] : a0.l[j];
+    int32_t hi = (s & 1) ? a3.l[j] : a2.l[j];
+    r.l[j] = (s & 2) ? hi : lo;
+  }
+}
+
+template <int J, class F>
+__device__ __forceinline__ void fe_quad_bcast(Fe<F>& r, const Fe<F>& a) {   // r = a of sub-lane J of the quad
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = __builtin_amdgcn_update_dpp(0, a.l[j], J * 0x55, 0xf, 0xf, false);
+}
+
+template <class F>
+__device__ __forceinline__ void xyzz_add_x4(Xyzz<F>& r, const Xyzz<F>& p, const Xyzz<F>& q, int s) {
+  const bool pinf = xyzz_is_inf(p), qinf = xyzz_is_inf(q);
+  Fe<F> a, b, m, U1, U2, S1, S2, P, R, PP, RR, Zm, Zc, PPP, Q, t, u;
+  fe_sel4(a, s, p.X, q.X, p.Y, q.Y);
+  fe_sel4(b, s, q.ZZ, p.ZZ, q.ZZZ, p.ZZZ);
+  fe_mul(m, a, b);
+  fe_quad_bcast<0>(U1, m);
+  fe_quad_bcast<1>(U2, m);
+  fe_quad_bcast<2>(S1, m);
+  fe_quad_bcast<3>(S2, m);
+  fe_sub(P, U2, U1);
+  fe_sub(R, S2, S1);
+  fe_sel4(a, s, P, R, p.ZZ, p.ZZZ);
+  fe_sel4(b, s, P, R, q.ZZ, q.ZZZ);
+  fe_mul(m, a, b);
+  fe_quad_bcast<0>(PP, m);
+  fe_quad_bcast<1>(RR, m);
+  fe_quad_bcast<2>(Zm, m);
+  fe_quad_bcast<3>(Zc, m);
+  fe_sel4(a, s, P, U1, Zm, Zm);
+  fe_mul(m, a, PP);
+  fe_quad_bcast<0>(PPP, m);
+  fe_quad_bcast<1>(Q, m);
+  fe_quad_bcast<2>(r.ZZ, m);
+  fe_sub(t, RR, PPP);
+  fe_sub(t, t, Q);
+  fe_sub(u, t, Q);       // X3
+  fe_carry(u);
+  fe_sub(t, Q, u);
+  fe_carry(t);
+  fe_sel4(a, s, R, S1, Zc, Zc);
+  fe_sel4(b, s, t, PPP, PPP, PPP);
+  fe_mul(m, a, b);
+  fe_quad_bcast<0>(Q, m);
+  fe_quad_bcast<1>(t, m);
+  fe_quad_bcast<2>(r.ZZZ, m);
+  fe_sub(r.Y, Q, t);
+  fe_carry(r.Y);
+  r.X = u;
+  // edge cases exactly as xyzz_add (uniform over the quad: all four lanes hold the same operands)
+  if (pinf) {
+    r = q;
+  } else if (qinf) {
+    r = p;
+  } else if (fe_is_zero(P)) {
+    if (fe_is_zero(R)) xyzz_dbl(r, p); else xyzz_set_inf(r);
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void te_add_x4(TeExt<F>& r, const TeExt<F>& p, const TeExt<F>& q, int s) {
+  Fe<F> a, b, m, A, B, C, D, E, Fv, G, H, t, u, v, w, k;
+  fe_sub(t, p.Y, p.X);
+  fe_sub(u, q.Y, q.X);
+  fe_carry(t);
+  fe_carry(u);
+  fe_add(v, p.Y, p.X);
+  fe_add(w, q.Y, q.X);
+  fe_carry(v);
+  fe_carry(w);
+  fe_sel4(a, s, t, v, p.T, p.Z);
+  fe_sel4(b, s, u, w, q.T, q.Z);
+  fe_mul(m, a, b);
+  fe_quad_bcast<0>(A, m);
+  fe_quad_bcast<1>(B, m);
+  fe_quad_bcast<2>(t, m);
+  fe_quad_bcast<3>(D, m);
+  fe_set_const<F>(k, F::K2D);
+  fe_mul(C, t, k);
+  fe_add(D, D, D);
+  fe_sub(E, B, A);
+  fe_sub(Fv, D, C);
+  fe_add(G, D, C);
+  fe_add(H, B, A);
+  fe_carry(E);
+  fe_carry(Fv);
+  fe_carry(G);
+  fe_carry(H);
+  fe_sel4(a, s, E, G, E, Fv);
+  fe_sel4(b, s, Fv, H, H, G);
+  fe_mul(m, a, b);
+  fe_quad_bcast<0>(r.X, m);
+  fe_quad_bcast<1>(r.Y, m);
+  fe_quad_bcast<2>(r.T, m);
+  fe_quad_bcast<3>(r.Z, m);
+}
+
 // ------------------------------------------------------------------------------------------------ group policies
 // The bucket accumulation of the msmBasic path and the bucket reduction are written once over a small
 // "group policy": accumulator type + how to fold an input point record into it.
@@ -922,6 +1053,7 @@ struct WeierPolicy {
   static __device__ __forceinline__ void zero(Acc& a) { xyzz_set_inf(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { xyzz_add(r, a, b); }
   static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { xyzz_dbl(r, a); }
+  static __device__ __forceinline__ void add_x4(Acc& r, const Acc& a, const Acc& b, int s) { xyzz_add_x4(r, a, b, s); }
   static __device__ __forceinline__ void madd(Acc& r, const Acc& a, const uint32_t* rec, uint32_t neg) {
     Affine<F> p;
     bool inf = load_affine<F>(p, rec, neg);
@@ -951,6 +1083,7 @@ struct TePolicy {
   static __device__ __forceinline__ void zero(Acc& a) { te_set_zero(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { te_add(r, a, b); }
   static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { te_add(r, a, a); }
+  static __device__ __forceinline__ void add_x4(Acc& r, const Acc& a, const Acc& b, int s) { te_add_x4(r, a, b, s); }
   static __device__ __forceinline__ void madd(Acc& r, const Acc& a, const uint32_t* rec, uint32_t neg) {
     TeNiels<F> n;
     Fe<F> pad;
@@ -1190,5 +1323,55 @@ __global__ void __launch_bounds__(64, 2) k_reduce_quad(uint32_t* rows_out, uint3
   if (live && q == 0) P::store(rows_out + (size_t)grp * XW, c);
   if (live && q == 1) P::store(c_out + (size_t)grp * XW, c);
 }
+
+// k_reduce_quad with every lane replaced by a DPP quad running the 4-lane addition: 16 lanes per group of 4
+// elements, 4 x 4 dependent field products per level.  Used for the small upper levels (latency-bound).
+template <class P>
+__global__ void __launch_bounds__(64, 2) k_reduce_quad16(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+                                                         const uint32_t* c_in, uint32_t n_in, uint32_t groups,
+                                                         uint32_t total) {
+  constexpr int XW = P::ACC_WORDS;
+  using Acc = typename P::Acc;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t grp = t >> 4, q = (t >> 2) & 3;
+  const int s = (int)(t & 3);
+  const bool live = grp < total;
+  const uint32_t k = live ? grp / groups : 0, A = live ? grp - k * groups : 0;
+  const uint32_t e = A * 4 + q;
+  const int lane = threadIdx.x & 63, base_lane = (lane & ~15) + s;
+  Acc r, c, v, w, got;
+  P::zero(r);
+  P::zero(c);
+  if (live && e < n_in) {
+    P::load(r, rows_in + ((size_t)k * n_in + e) * XW);
+    P::load(c, c_in + ((size_t)k * n_in + e) * XW);
+  }
+  {
+    const int src[4] = {1, 3, 3, 2};
+    quad_fetch<P>(got, q == 2 ? c : r, base_lane + 4 * src[q]);
+    P::add_x4(v, q == 3 ? c : r, got, s);   // L0 s01, L1 b, L2 a, L3 c23
+  }
+  {
+    const int src[4] = {2, 0, 2, 3};
+    quad_fetch<P>(got, q == 0 ? c : v, base_lane + 4 * src[q]);
+    if (q == 3) P::zero(got);
+    Acc lhs = (q == 1) ? c : v;
+    if (q == 3) P::zero(lhs);
+    P::add_x4(w, lhs, got, s);              // L0 row, L1 c01, L2 2a, L3 0
+  }
+  {
+    const int src[4] = {0, 3, 1, 3};
+    quad_fetch<P>(got, q == 0 ? w : v, base_lane + 4 * src[q]);
+    P::add_x4(r, w, got, s);                // L0 2 row, L1 cs, L2 tri
+  }
+  {
+    const int src[4] = {0, 2, 2, 3};
+    quad_fetch<P>(got, r, base_lane + 4 * src[q]);
+    P::add_x4(c, r, got, s);                // L0 4 row, L1 C' = cs + tri
+  }
+  if (live && q == 0 && s == 0) P::store(rows_out + (size_t)grp * XW, c);
+  if (live && q == 1 && s == 0) P::store(c_out + (size_t)grp * XW, c);
+}
+
 
 }  // namespace msmz
