@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmsmz.so")
+LIB_PATH = os.environ.get("MSMZ_LIB") or os.path.join(HERE, "libmsmz.so")   # MSMZ_LIB: development builds
 
 MSMZ_N_STAGES = 8
 STAGE_NAMES = ["digits", "scan", "scatter", "plan", "accumulate", "reduce", "final", "total"]

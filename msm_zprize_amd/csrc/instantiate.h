@@ -32,8 +32,12 @@
 #ifndef MSMZ_BATCH_T
 #define MSMZ_BATCH_T 128
 #endif
-#define MSMZ_BATCH_OCC 2
+#ifndef MSMZ_BATCH_OCC
+#define MSMZ_BATCH_OCC 4
+#endif
+#ifndef MSMZ_BATCH_BMAX
 #define MSMZ_BATCH_BMAX 16
+#endif
 
 #define MSMZ_INST_BATCH_FUSED(F, SAFE, PFX)                                                                       \
   PFX template __global__ void k_batch_add_fused<F, MSMZ_BATCH_T, SAFE, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(         \
