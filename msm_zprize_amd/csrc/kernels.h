@@ -1106,6 +1106,9 @@ struct TePolicy {
 // Bucket accumulation without batch inversion (msm-basic.ts:106-128: addMixed / subMixed into projective
 // or extended buckets).  The sorted reference list of every bucket is cut into chunks of CH entries
 // (cscan = exclusive scan of ceil(size / CH), scan mode 2); one thread folds one chunk into an accumulator.
+#ifndef MSMZ_REDUCE_OCC
+#define MSMZ_REDUCE_OCC 2   // waves per SIMD the register budget of the big reduction kernels is capped for
+#endif
 constexpr int ACC_CHUNK = 64;
 
 template <class P>
@@ -1159,7 +1162,7 @@ __device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const 
 // simply adds up the tri's:  C'_A = sum_b C[AS + b] + tri'_A.  After the last level (one entry per
 // window) C is W_k.  No per-level power-of-two scaling of the partial sums is needed.
 template <class F>
-__global__ void __launch_bounds__(128, 2) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
+__global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
                                                       const uint32_t* points, const uint32_t* refs, const uint32_t* off,
                                                       uint32_t L, uint32_t S, uint32_t groups, uint32_t total,
                                                       const uint32_t* rscan_all, uint32_t nb, const MsmMeta* meta) {
@@ -1275,7 +1278,7 @@ __device__ __forceinline__ void quad_fetch(typename P::Acc& got, const typename 
 }
 
 template <class P>
-__global__ void __launch_bounds__(64, 2) k_reduce_quad(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+__global__ void __launch_bounds__(64, MSMZ_REDUCE_OCC) k_reduce_quad(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
                                                     const uint32_t* c_in, uint32_t n_in, uint32_t groups,
                                                     uint32_t total) {
   constexpr int XW = P::ACC_WORDS;

@@ -14,5 +14,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/profile_msm.py --reps 2 > /dev/null 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/pmc_fetch > $OUT/${TAG}_pmc_fetch_summary.txt
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/pmc_write > $OUT/${TAG}_pmc_write_summary.txt
+python3 $GRAFT_REPO_ROOT/tools/make_scatter_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_scatter_pmc.json 15 20
 rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/pmc_fetch/*/*kernel_trace.csv $OUT/pmc_write/*/*kernel_trace.csv
 echo collected
