@@ -315,48 +315,95 @@ class Engine : public IEngine {
     return ms;
   }
 
-  int make_plan(Plan& pl, uint64_t n64, bool glv, const msmz_opts& opt, uint32_t pts_n) {
-    pl.n = (uint32_t)n64;
-    pl.glv = glv;
-    pl.M = glv ? 2 * pl.n : pl.n;
-    pl.b = glv ? Fr::GLV_BITS - 1 : Fr::BITS;                 // scalar bit length
-    pl.c = opt.c > 0 ? opt.c : default_window(pl.M);
-    if (opt.c <= 0) {
-      // avoid a nearly empty top window (all its entries would share a few buckets): step c down until the
-      // top window keeps at least c - 4 significant bits (the rest is handled by sub-window spreading)
-      for (int tries = 0; tries < 3 && pl.c > 4; tries++) {
-        const int K0 = (pl.b + 1 + pl.c - 1) / pl.c;
-        const int top_bits = pl.b + 1 - (K0 - 1) * pl.c;
-        if (K0 == 1 || top_bits >= pl.c - 4) break;
-        pl.c--;
-      }
-    }
-    if (pl.c < 2) pl.c = 2;
-    if (pl.c > 24) pl.c = 24;
-    pl.K = (pl.b + 1 + pl.c - 1) / pl.c;                      // msm-batched-affine.ts:96
-    pl.L = 1u << (pl.c - 1);
-    // significant bits of the top window's digit (from the actual largest scalar, q - 1, or the GLV bound);
-    // spread it over 2^sb sub-windows when it is sparse
-    int t_top = pl.b + 1 - (pl.K - 1) * pl.c;
+  // Window geometry for window size c: K windows, L buckets each, significant bits t_top of the top window's
+  // digit (from the largest scalar q - 1, or the typical GLV half), and the 2^spread sub-windows the top window
+  // is spread over when it is sparse.
+  struct Geometry {
+    int c, K, t_top, spread, Keff;
+    uint32_t L;
+  };
+  Geometry geometry(int c, bool glv, uint32_t M, int b) const {
+    Geometry g;
+    g.c = c;
+    g.K = (b + 1 + c - 1) / c;                              // msm-batched-affine.ts:96
+    g.L = 1u << (c - 1);
+    const int pos = (g.K - 1) * c;
+    g.t_top = b + 1 - pos;
     if (!glv) {
-      const int pos = (pl.K - 1) * pl.c;
       uint64_t top = 0;
       for (int j = 0; j < 64 && pos + j < 256; j++)
         top |= (uint64_t)((Fr::Q[(pos + j) >> 5] >> ((pos + j) & 31)) & 1u) << j;
       top += 1;   // carry from the window below
-      t_top = ceil_log2_u64(top + 1);
+      g.t_top = ceil_log2_u64(top + 1);
+    } else if (Fr::GLV_TYP_BITS + 1 - pos < g.t_top) {
+      g.t_top = Fr::GLV_TYP_BITS + 1 - pos;
+      if (g.t_top < 1) g.t_top = 1;
     }
-    pl.spread = 0;
-    if (!no_spread_ && pl.K > 1 && t_top <= pl.c - 2) {
-      pl.spread = pl.c - 1 - t_top;
-      if (pl.spread > 3) pl.spread = 3;
-      const int ib = ceil_log2_u64(pl.M < 2 ? 2 : pl.M);
+    g.spread = 0;
+    if (!no_spread_ && g.K > 1 && g.t_top <= c - 2) {
+      g.spread = c - 1 - g.t_top;
+      if (g.spread > 3) g.spread = 3;
+      const int ib = ceil_log2_u64(M < 2 ? 2 : M);
       int fbm = 31 - ib > FINE_MAX_BITS ? FINE_MAX_BITS : 31 - ib;
       if (fb_cap_ > 0 && fbm > fb_cap_) fbm = fb_cap_;
-      const int fbx = (pl.c - 1) < fbm ? (pl.c - 1) : fbm;
-      while (pl.spread > 0 && ((pl.L >> fbx) << pl.spread) > (uint32_t)COARSE_MAX_BINS) pl.spread--;
+      const int fbx = (c - 1) < fbm ? (c - 1) : fbm;
+      while (g.spread > 0 && ((g.L >> fbx) << g.spread) > (uint32_t)COARSE_MAX_BINS) g.spread--;
     }
-    pl.Keff = pl.K - 1 + (1 << pl.spread);
+    g.Keff = g.K - 1 + (1 << g.spread);
+    return g;
+  }
+
+  // Default window size.  Large inputs (M >= 2^19) are throughput-bound: c = log2 M - 3 capped at 17, stepped
+  // down while the top window would be nearly empty.  Smaller inputs are latency-bound -- every tree round costs
+  // ~75 us whatever its size and the number of rounds is log2 of the LONGEST bucket, which usually sits in a
+  // partly filled top window -- so they pick the c that minimizes a small cost model fitted to this GPU
+  // (ms: rounds * 0.075 + additions / 4.5e6 + reduction levels * 0.065 + buckets * 0.8e-6).
+  int choose_window(bool glv, uint32_t M, int b, bool tree_rounds) const {
+    int c = default_window(M);
+    if (M >= (1u << 19) || no_window_model_) {
+      for (int tries = 0; tries < 3 && c > 4; tries++) {
+        const int K0 = (b + 1 + c - 1) / c;
+        const int top_bits = b + 1 - (K0 - 1) * c;
+        if (K0 == 1 || top_bits >= c - 4) break;
+        c--;
+      }
+      return c;
+    }
+    const int lg = ceil_log2_u64(M < 2 ? 2 : M);
+    int best_c = c;
+    double best = 1e30;
+    for (int cc = (lg - 6 < 3 ? 3 : lg - 6); cc <= (lg + 2 > 17 ? 17 : lg + 2); cc++) {
+      const Geometry g = geometry(cc, glv, M, b);
+      if (g.Keff > kMaxWindows) continue;
+      const double lam = (double)M / g.L;
+      const double conc = g.t_top < cc ? (double)(1u << (cc - g.t_top)) / (1 << g.spread) : 1.0;
+      double maxb = 1.5 * lam + 12;
+      if (g.K > 1 && conc * lam * 1.3 + 12 > maxb) maxb = conc * lam * 1.3 + 12;
+      if (maxb > M) maxb = M;
+      const int rounds = ceil_log2_u64((uint64_t)(maxb < 2 ? 2 : maxb));
+      const double cost = (tree_rounds ? 0.075 * rounds : 0.0) + (double)g.K * M / 4.5e6 + 0.065 * ((cc - 1 + 1) / 2) +
+                          0.8e-6 * g.Keff * g.L;
+      if (cost < best) {
+        best = cost;
+        best_c = cc;
+      }
+    }
+    return best_c;
+  }
+
+  int make_plan(Plan& pl, uint64_t n64, bool glv, const msmz_opts& opt, uint32_t pts_n, bool tree_rounds = true) {
+    pl.n = (uint32_t)n64;
+    pl.glv = glv;
+    pl.M = glv ? 2 * pl.n : pl.n;
+    pl.b = glv ? Fr::GLV_BITS - 1 : Fr::BITS;                 // scalar bit length
+    pl.c = opt.c > 0 ? opt.c : choose_window(glv, pl.M, pl.b, tree_rounds);
+    if (pl.c < 2) pl.c = 2;
+    if (pl.c > 24) pl.c = 24;
+    const Geometry g = geometry(pl.c, glv, pl.M, pl.b);
+    pl.K = g.K;
+    pl.L = g.L;
+    pl.spread = g.spread;
+    pl.Keff = g.Keff;
     const uint64_t nb64 = (uint64_t)pl.Keff * pl.L;
     if (nb64 + 1 >= (1ull << 31) || (uint64_t)pl.K * pl.M >= (1ull << 32) || pl.Keff > kMaxWindows) return MSMZ_ERR_ARG;
     pl.nb = (uint32_t)nb64;
@@ -706,7 +753,7 @@ class Engine : public IEngine {
   // (msm-basic.ts:45-176; Weierstrass "projective fallback" parallel.ts:69-87 and the twisted-Edwards MSM)
   template <class P>
   int msm_basic(const Handle& pts, const uint32_t* d_scalars, uint64_t n64, const msmz_opts& opt, Plan& pl) {
-    int st = make_plan(pl, n64, false, opt, (uint32_t)pts.n);
+    int st = make_plan(pl, n64, false, opt, (uint32_t)pts.n, false);
     if (st) return st;
     if ((st = sort_phase(pl, d_scalars))) return st;
     constexpr int AW = P::ACC_WORDS;
@@ -935,6 +982,7 @@ class Engine : public IEngine {
   bool no_quad_ = getenv("MSMZ_NO_QUAD") != nullptr;
   uint32_t quad16_max_groups_ = getenv("MSMZ_QUAD16") ? (uint32_t)atoi(getenv("MSMZ_QUAD16")) : 8192u;   // levels with at most this many groups use k_reduce_quad16
   bool no_spread_ = getenv("MSMZ_NO_SPREAD") != nullptr;
+  bool no_window_model_ = getenv("MSMZ_NO_WINDOW_MODEL") != nullptr;
   bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
   int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
   DevBuf wgfirst_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
