@@ -657,8 +657,11 @@ class Engine : public IEngine {
     if ((st = sort_phase(pl, d_scalars))) return st;
     const uint32_t nb = pl.nb, nblocks = pl.nblocks;
     MsmMeta* d_meta = meta_.as<MsmMeta>();
-    const int R = pl.max_bucket <= 1 ? 0 : ceil_log2_u64(pl.max_bucket);   // rounds m = 1, 2, 4, ... < max_bucket
-    if (R > 31) return MSMZ_ERR_ARG;
+    const int Rfull = pl.max_bucket <= 1 ? 0 : ceil_log2_u64(pl.max_bucket);   // rounds m = 1, 2, 4, ... < max_bucket
+    if (Rfull > 31) return MSMZ_ERR_ARG;
+    // The last rounds only touch the few longest buckets but cost a full round of latency each: stop `tail_skip_`
+    // rounds early and let the reduction's loader add up the <= 2^tail_skip_ partial sums such a bucket is left with.
+    const int R = Rfull <= 1 ? Rfull : (Rfull - tail_skip_ < 1 ? 1 : Rfull - tail_skip_);
 
     const int ev_plan0 = pl.ei;
     mark(pl);
@@ -733,7 +736,7 @@ class Engine : public IEngine {
       uint32_t total = pl.Keff * groups;
       hipLaunchKernelGGL((k_reduce_first<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
                          red_[0].as<uint32_t>(), red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points,
-                         refs_.as<uint32_t>(), off_.as<uint32_t>(), pl.L, S1, groups, total, rscan_.as<uint32_t>(), nb,
+                         refs_.as<uint32_t>(), off_.as<uint32_t>(), pl.L, S1, groups, total, rscan_.as<uint32_t>(), nb, R,
                          d_meta);
     }
     int cur = 0;
@@ -970,7 +973,8 @@ class Engine : public IEngine {
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
   uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 2048u;
-  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 512u;
+  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 1024u;
+  int tail_skip_ = getenv("MSMZ_TAIL_SKIP") ? atoi(getenv("MSMZ_TAIL_SKIP")) : 2;
   uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
   int fb_cap_ = getenv("MSMZ_FB") ? atoi(getenv("MSMZ_FB")) : 0;
   uint32_t s1_override_ = getenv("MSMZ_S1") ? (uint32_t)atoi(getenv("MSMZ_S1")) : 0u;

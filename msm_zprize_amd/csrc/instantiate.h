@@ -65,7 +65,7 @@
 #define MSMZ_INST_REDUCE(F, Fr, PFX)                                                                              \
   PFX template __global__ void k_reduce_first<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
                                                  const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,   \
-                                                 uint32_t, const uint32_t*, uint32_t, const MsmMeta*);            \
+                                                 uint32_t, const uint32_t*, uint32_t, int, const MsmMeta*);       \
   MSMZ_INST_POLICY(WeierPolicy<F>, PFX)
 
 #define MSMZ_INST_REDUCE_TE(F, Fr, PFX) MSMZ_INST_POLICY(TePolicy<F>, PFX)

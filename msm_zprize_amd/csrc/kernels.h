@@ -821,9 +821,14 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
       const uint32_t start = off[g], size = off[g + 1] - start;
       const uint32_t a = (t - rscan[g]) * 2 * m, b = a + m;
       const uint32_t locA = element_location(g, start, size, a, r, refs, rscan_all, nb, meta);
-      const uint32_t locB = element_location(g, start, size, b, r, refs, rscan_all, nb, meta);
+      uint32_t locB = element_location(g, start, size, b, r, refs, rscan_all, nb, meta);
+      uint32_t locA_dbg = locA;
+      if ((dbg & 4u) && r == 0) {   // timing experiment: sequential instead of gathered operands (2^20 inputs)
+        locA_dbg = LOC_ORIG | ((2u * t) & 0xfffffu);
+        locB = LOC_ORIG | ((2u * t + 1u) & 0xfffffu);
+      }
       uint32_t negA, negB;
-      const uint32_t* recA = location_record<F>(locA, slots, points, negA);
+      const uint32_t* recA = location_record<F>(locA_dbg, slots, points, negA);
       const uint32_t* recB = location_record<F>(locB, slots, points, negB);
       Affine<F> p1, p2;
       bool infA = load_affine<F>(p1, recA, negA);
@@ -1275,22 +1280,27 @@ __global__ void __launch_bounds__(128) k_bucket_accumulate(uint32_t* partial, co
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
-// Bucket sum of global bucket g after all tree rounds: empty -> infinity; one element -> the original
-// point; otherwise the result of the last round in which position 0 had a partner.
+// run += (sum of bucket g).  After `rounds_done` tree rounds a bucket of `size` elements is left as
+// ceil(size / 2^rounds_done) partial sums (one for all but the longest buckets: the host stops the tree rounds two
+// short of log2(longest bucket), because a round costs ~80 us of latency however few pairs it has); partial sum i
+// covers the elements from position i * 2^rounds_done and lives where element_location says.
 template <class F>
-__device__ __forceinline__ bool load_bucket_sum(Affine<F>& p, uint32_t g, const uint32_t* slots, const uint32_t* points,
-                                                const uint32_t* refs, const uint32_t* off, const uint32_t* rscan_all,
-                                                uint32_t nb, const MsmMeta* meta) {
-  constexpr int RW = 2 * F::NW;
-  uint32_t start = off[g], size = off[g + 1] - start;
-  if (size == 0) return true;
-  if (size == 1) {
-    uint32_t rf = refs[start];
-    return load_affine<F>(p, points + (size_t)(rf & REF_IDX) * RW, rf >> 31);
+__device__ __forceinline__ void add_bucket(Xyzz<F>& run, uint32_t g, const uint32_t* slots, const uint32_t* points,
+                                           const uint32_t* refs, const uint32_t* off, const uint32_t* rscan_all,
+                                           uint32_t nb, int rounds_done, const MsmMeta* meta) {
+  const uint32_t start = off[g], size = off[g + 1] - start;
+  const uint32_t step = 1u << rounds_done;
+#pragma unroll 1
+  for (uint32_t pos = 0; pos < size; pos += step) {
+    const uint32_t loc = element_location(g, start, size, pos, rounds_done, refs, rscan_all, nb, meta);
+    uint32_t neg;
+    const uint32_t* rec = location_record<F>(loc, slots, points, neg);
+    Affine<F> p;
+    const bool inf = load_affine<F>(p, rec, neg);
+    Xyzz<F> tmp;
+    xyzz_madd(tmp, run, p, inf);
+    run = tmp;
   }
-  const int rr = 31 - __builtin_clz(size - 1);
-  const uint32_t rec = meta->round_base[rr] + rscan_all[(size_t)rr * ((size_t)nb + 1) + g];
-  return load_affine<F>(p, slots + (size_t)rec * RW, 0);
 }
 
 // Bucket reduction  W_k = sum_{l=1..L} l * B_l  (msm-batched-affine.ts:544-571) by grouped running sums.
@@ -1305,7 +1315,8 @@ template <class F>
 __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
                                                       const uint32_t* points, const uint32_t* refs, const uint32_t* off,
                                                       uint32_t L, uint32_t S, uint32_t groups, uint32_t total,
-                                                      const uint32_t* rscan_all, uint32_t nb, const MsmMeta* meta) {
+                                                      const uint32_t* rscan_all, uint32_t nb, int rounds_done,
+                                                      const MsmMeta* meta) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t k = t / groups, a = t - k * groups;
@@ -1314,18 +1325,11 @@ __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce_first(uint32_t*
   xyzz_set_inf(tri);
   for (uint32_t b = S; b-- > 0;) {
     const uint32_t j = a * S + b;           // weight; bucket l = j, j in [0, L)
-    Affine<F> p;
-    bool inf = (j == 0 || j >= L) ? true
-                                   : load_bucket_sum<F>(p, k * L + (j - 1), slots, points, refs, off, rscan_all, nb, meta);
-    xyzz_madd(tmp, run, p, inf);
-    run = tmp;
+    if (j >= 1 && j < L) add_bucket<F>(run, k * L + (j - 1), slots, points, refs, off, rscan_all, nb, rounds_done, meta);
     if (j == L / 2 && L >= 2) {
       // the single bucket of weight L is folded in as 2 * (L/2): keeps the element count a power of two
-      bool inf2 = load_bucket_sum<F>(p, k * L + (L - 1), slots, points, refs, off, rscan_all, nb, meta);
-      xyzz_madd(tmp, run, p, inf2);
-      run = tmp;
-      xyzz_madd(tmp, run, p, inf2);
-      run = tmp;
+      for (int twice = 0; twice < 2; twice++)
+        add_bucket<F>(run, k * L + (L - 1), slots, points, refs, off, rscan_all, nb, rounds_done, meta);
     }
     if (b >= 1) {
       xyzz_add(tmp, tri, run);
