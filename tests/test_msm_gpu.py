@@ -175,6 +175,34 @@ def test_safe_path_edge_cases(curves):
         assert curve.Parallel.msmProjective(sc, pts, len(points))["result"] == want
 
 
+@pytest.mark.parametrize("label", ["bls12-377", "pallas"])
+def test_long_buckets(curves, label):
+    """Heavily repeated scalars: a few buckets hold hundreds of (distinct) points, so the pair tree runs many
+    rounds, stops short of the longest bucket and the reduction adds the leftover partial sums; the reference's
+    counterpart is the same-scalar case of src/bigint/msm.test.ts:47-56."""
+    curve = curves(label)
+    c = P.CURVES[label]
+    q = c["order"]
+    rng = random.Random(77)
+    n = 700
+    pts = curve.Parallel.randomPointsFast(n, 4242)
+    points = curve.Affine.toBigints(pts)
+    s1, s2 = rng.randrange(q), rng.randrange(q)
+    for scalars in ([s1] * n,
+                    [s1 if i % 3 else s2 for i in range(n)],
+                    [s1 if i < 500 else rng.randrange(q) for i in range(n)],
+                    [q - 1] * n):
+        want = _oracle(label, scalars, points)
+        sc = curve.Parallel.scalarsFromBigints(scalars)
+        for glv in (0, 1):
+            for cc in (0, 4, 9):
+                assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": glv, "c": cc})["result"] == want, (glv, cc)
+            assert curve.Parallel.msm(sc, pts, n, False, {"glv": glv})["result"] == want
+        assert curve.Parallel.msmProjective(sc, pts, n)["result"] == want
+        sc.free()
+    pts.free()
+
+
 def test_unsafe_reports_degenerate_batch(curves):
     """msmUnsafe on equal points: the reference traps (inverse.ts:198-199); here a status is returned"""
     import msm_zprize_amd._native as nat
