@@ -129,3 +129,13 @@ def test_glv_decompose(driver, field, params):
         assert s0 < (1 << 127) and s1 < (1 << 127)
         v = (-s0 if n0 == "1" else s0) + (-s1 if n1 == "1" else s1) * lam
         assert (v - x) % q == 0, hex(x)
+
+
+def test_host64_matches_limb_arithmetic():
+    """csrc/host64.h (64-bit limbs, same Montgomery radix) == fp.h / curve.h on the host"""
+    src = os.path.join(ROOT, "tests", "native", "host64_test.cpp")
+    exe = os.path.join(ROOT, "tests", "native", "host64_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("mismatches 0") == 3, r.stdout
