@@ -571,12 +571,11 @@ class Engine : public IEngine {
     return S1 < pl.L ? S1 : pl.L;
   }
 
-  // copy the K (row, C) pairs to the host
+  // copy the K window sums (the C entries of the last level; its rows are multiples of L and not needed) to the host
   template <class P>
   int fetch_window_sums(const Plan& pl, int cur) {
     constexpr int AW = P::ACC_WORDS;
     MSMZ_HIP(hipGetLastError());
-    MSMZ_HIP(hipMemcpyAsync(h_final_, red_[cur * 2].p, (size_t)pl.Keff * AW * 4, hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, red_[cur * 2 + 1].p, (size_t)pl.Keff * AW * 4,
                             hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipMemcpyAsync(h_meta_, meta_.p, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
@@ -584,7 +583,7 @@ class Engine : public IEngine {
     return MSMZ_OK;
   }
 
-  // final sum on the host (msm-batched-affine.ts:300-322): W_k = C_k + row_k, Horner over windows
+  // final sum on the host (msm-batched-affine.ts:300-322): W_k = C_k of the last level, Horner over windows
   void finalize_weierstrass(const Plan& pl, uint8_t* out, int* out_inf) {
     // ~K*c dependent doublings: on 64-bit limbs (host64.h), ~4x faster on a CPU core than the kernels' limb code
     using H = Host64<F>;
