@@ -131,7 +131,9 @@ def main():
                        "log2n_per_gpu": log2n, "c": c, "K": K, "glv": bool(args.glv),
                        "point_adds_per_msm": total_entries / args.steps / world, "sharding": f"input-split x{world}"},
             "roofline": {"kernel": "k_scatter_coarse", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": scatter_traffic(),
+                         "frac": achieved / 8000.0,
+                         # PMC bytes were collected on the 2^20 no-GLV workload only
+                         "traffic": scatter_traffic() if (log2n == 20 and not args.glv) else None,
                          "bytes_per_launch": scatter_bytes, "avg_launch_ms": scatter_ms},
             "valu_roofline": {"kernel": "k_batch_add (all rounds)", "bound": "int32 VALU (v_mad_i64_i32)",
                               "achieved": pairs * 6 / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
