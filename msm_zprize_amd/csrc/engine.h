@@ -654,7 +654,7 @@ class Engine : public IEngine {
     if (st) return st;
     // sorted positions are packed into 28 bits inside k_batch_add
     if ((uint64_t)pl.K * pl.M >= (1ull << 28)) return MSMZ_ERR_ARG;
-    if ((st = slots_.ensure((size_t)pl.K * pl.M * RW * 4))) return st;
+    if ((st = slots_.ensure(((size_t)pl.K * pl.M + 64) * RW * 4))) return st;   // whole groups of 64 records
     if ((st = sort_phase(pl, d_scalars))) return st;
     const uint32_t nb = pl.nb, nblocks = pl.nblocks;
     MsmMeta* d_meta = meta_.as<MsmMeta>();

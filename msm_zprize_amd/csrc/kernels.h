@@ -46,13 +46,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // k_batch_add 1.7x SLOWER (round 0: 1.9 -> 3.9 ms) -- the backward pass re-reads what the forward pass parked
 // (z, x1) and lives off L2 / Infinity Cache hits -- so SLOT_NT stays false.
 constexpr bool SLOT_NT = false;
+// `cs` = distance between a record's consecutive 16-byte chunks, in chunks: 1 for ordinary records, SLOT_CS for
+// the chunk-interleaved slot arrays (below).
 template <class F, bool NT = false>
-__device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src) {
+__device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src, int cs = 1) {
   // records are 16-byte aligned: 2*NW words = 96 B / 64 B
   const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
 #pragma unroll
   for (int i = 0; i < (2 * F::NW) / 4; i++) {
-    u32x4 v = NT ? __builtin_nontemporal_load(s4 + i) : s4[i];
+    u32x4 v = NT ? __builtin_nontemporal_load(s4 + i * cs) : s4[i * cs];
     dst[4 * i] = v.x;
     dst[4 * i + 1] = v.y;
     dst[4 * i + 2] = v.z;
@@ -61,20 +63,20 @@ __device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* src) {
 }
 
 template <class F, bool NT = false>
-__device__ __forceinline__ void store_words(uint32_t* dst, const uint32_t* src) {
+__device__ __forceinline__ void store_words(uint32_t* dst, const uint32_t* src, int cs = 1) {
   u32x4* d4 = reinterpret_cast<u32x4*>(dst);
 #pragma unroll
   for (int i = 0; i < (2 * F::NW) / 4; i++) {
     u32x4 v = {src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
-    if (NT) __builtin_nontemporal_store(v, d4 + i); else d4[i] = v;
+    if (NT) __builtin_nontemporal_store(v, d4 + i * cs); else d4[i * cs] = v;
   }
 }
 
 // load an affine point record; returns true if it is the point at infinity
 template <class F, bool NT = false>
-__device__ __forceinline__ bool load_affine(Affine<F>& p, const uint32_t* rec, uint32_t negate) {
+__device__ __forceinline__ bool load_affine(Affine<F>& p, const uint32_t* rec, uint32_t negate, int cs = 1) {
   uint32_t w[2 * F::NW];
-  load_words<F, NT>(w, rec);
+  load_words<F, NT>(w, rec, cs);
   uint32_t o = 0;
 #pragma unroll
   for (int i = 0; i < 2 * F::NW; i++) o |= w[i];
@@ -86,7 +88,7 @@ __device__ __forceinline__ bool load_affine(Affine<F>& p, const uint32_t* rec, u
 }
 
 template <class F, bool NT = false>
-__device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, bool inf) {
+__device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, bool inf, int cs = 1) {
   uint32_t w[2 * F::NW];
   if (inf) {
 #pragma unroll
@@ -96,7 +98,18 @@ __device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, 
     fe_store<F>(w + F::NW, p.y);
     // a finite point can never serialize to the all-zero record: x = y = 0 is not on the curve
   }
-  store_words<F, NT>(rec, w);
+  store_words<F, NT>(rec, w, cs);
+}
+
+// Slot arrays (results of the tree rounds) are chunk-interleaved in groups of 64 records: chunk q (16 bytes) of
+// record r sits at 16-byte unit (r / 64) * 64 * CH + q * 64 + r % 64, CH = chunks per record.  A wave whose lanes hold
+// consecutive records (the writers) then moves one contiguous KB per load/store instruction, and the readers of the
+// next round (lane i wants records 2i, 2i + 1) two KB, instead of 64 pieces 96 bytes apart.
+constexpr int SLOT_CS = 64;
+template <class F>
+__device__ __forceinline__ size_t slot_offset(uint32_t rec) {   // in 32-bit words
+  constexpr int CH = (2 * F::NW) / 4;
+  return ((size_t)(rec >> 6) * (CH * 64) + (rec & 63u)) * 4;
 }
 
 template <class F>
@@ -619,14 +632,16 @@ __device__ __forceinline__ uint32_t element_location(uint32_t g, uint32_t start,
 
 template <class F>
 __device__ __forceinline__ const uint32_t* location_record(uint32_t loc, const uint32_t* slots, const uint32_t* points,
-                                                           uint32_t& neg) {
+                                                           uint32_t& neg, int& cs) {
   constexpr int RW = 2 * F::NW;
   if (loc & LOC_ORIG) {
     neg = loc >> 31;
+    cs = 1;
     return points + (size_t)(loc & 0x3fffffffu) * RW;
   }
   neg = 0;
-  return slots + (size_t)loc * RW;
+  cs = SLOT_CS;
+  return slots + slot_offset<F>(loc);
 }
 
 // ------------------------------------------------------------------------------------------------ wave-wide inversion
@@ -828,11 +843,12 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
         locB = LOC_ORIG | ((2u * t + 1u) & 0xfffffu);
       }
       uint32_t negA, negB;
-      const uint32_t* recA = location_record<F>(locA_dbg, slots, points, negA);
-      const uint32_t* recB = location_record<F>(locB, slots, points, negB);
+      int csA, csB;
+      const uint32_t* recA = location_record<F>(locA_dbg, slots, points, negA, csA);
+      const uint32_t* recB = location_record<F>(locB, slots, points, negB, csB);
       Affine<F> p1, p2;
-      bool infA = load_affine<F>(p1, recA, negA);
-      bool infB = load_affine<F>(p2, recB, negB);
+      bool infA = load_affine<F>(p1, recA, negA, csA);
+      bool infB = load_affine<F>(p2, recB, negB, csB);
       Fe<F> d, num;
       fe_sub(d, p2.x, p1.x);
       fe_sub(num, p2.y, p1.y);
@@ -864,15 +880,15 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
         fe_mul(z, prefix, num);
         uint32_t w[NW];
         fe_store_mulout<F>(w, z);
-        uint32_t* out = slots + (size_t)(out_base + t) * RW;
+        uint32_t* out = slots + slot_offset<F>(out_base + t);
         const u32x4* a4 = reinterpret_cast<const u32x4*>(recA);
         u32x4* o4 = reinterpret_cast<u32x4*>(out);
 #pragma unroll
-        for (int q = 0; q < NW / 4; q++) o4[q] = a4[q];
+        for (int q = 0; q < NW / 4; q++) o4[q * SLOT_CS] = a4[q * csA];
 #pragma unroll
         for (int q = 0; q < NW / 4; q++) {
           u32x4 v = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
-          o4[NW / 4 + q] = v;
+          o4[(NW / 4 + q) * SLOT_CS] = v;
         }
         Fe<F> np;
         fe_mul(np, prefix, d);
@@ -969,16 +985,17 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
     const uint32_t kind = s_kind[i * T + threadIdx.x];
     if (kind == PK_NONE) continue;
     const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
-    uint32_t* out = slots + (size_t)(out_base + t) * RW;
+    uint32_t* out = slots + slot_offset<F>(out_base + t);
     uint32_t neg;
-    const uint32_t* rec = location_record<F>(s_loc[i * T + threadIdx.x], slots, points, neg);
+    int cs;
+    const uint32_t* rec = location_record<F>(s_loc[i * T + threadIdx.x], slots, points, neg, cs);
     if (kind == PK_ADD || kind == PK_DBL) {
       Affine<F> p2;
-      load_affine<F>(p2, rec, neg);
+      load_affine<F>(p2, rec, neg, cs);
       Fe<F> x1, z, mm, ms, d, tt;
       {
         uint32_t w[RW];
-        load_words<F>(w, out);            // [x1 | z] parked by the forward pass
+        load_words<F>(w, out, SLOT_CS);   // [x1 | z] parked by the forward pass
         fe_unpack<F>(x1, w);
         fe_unpack<F>(z, w + NW);
       }
@@ -998,14 +1015,14 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
       fe_carry(tt);
       fe_mul(ms, mm, tt);
       fe_sub(res.y, ms, p2.y);            // y3 = m (x2 - x3) - y2
-      store_affine<F>(out, res, false);
+      store_affine<F>(out, res, false, SLOT_CS);
     } else if (kind == PK_TAKE_A || kind == PK_TAKE_B) {
       Affine<F> p;
-      load_affine<F>(p, rec, neg);
-      store_affine<F>(out, p, false);
+      load_affine<F>(p, rec, neg, cs);
+      store_affine<F>(out, p, false, SLOT_CS);
     } else {                              // PK_INF
       Affine<F> dummy;
-      store_affine<F>(out, dummy, true);
+      store_affine<F>(out, dummy, true, SLOT_CS);
     }
   }
 }
@@ -1294,9 +1311,10 @@ __device__ __forceinline__ void add_bucket(Xyzz<F>& run, uint32_t g, const uint3
   for (uint32_t pos = 0; pos < size; pos += step) {
     const uint32_t loc = element_location(g, start, size, pos, rounds_done, refs, rscan_all, nb, meta);
     uint32_t neg;
-    const uint32_t* rec = location_record<F>(loc, slots, points, neg);
+    int cs;
+    const uint32_t* rec = location_record<F>(loc, slots, points, neg, cs);
     Affine<F> p;
-    const bool inf = load_affine<F>(p, rec, neg);
+    const bool inf = load_affine<F>(p, rec, neg, cs);
     Xyzz<F> tmp;
     xyzz_madd(tmp, run, p, inf);
     run = tmp;
