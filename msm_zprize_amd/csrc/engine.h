@@ -708,19 +708,42 @@ class Engine : public IEngine {
         if (opt.safe != 0) {
           hipLaunchKernelGGL((k_batch_add_fused<F, T, true, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
                              slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>());
+                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), 0);
         } else {
           hipLaunchKernelGGL((k_batch_add_fused<F, T, false, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
                              slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>());
+                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), 0);
         }
       }
       mark(pl);
     } else {
-      for (int r = 0; r < R; r++) {
+      // experiment (MSMZ_FUSE_TAIL=n): the last n rounds in one launch, each workgroup owning a range of buckets
+      const int r_fuse = (fuse_tail_ >= 2 && R > fuse_tail_) ? R - fuse_tail_ : R;
+      for (int r = 0; r < r_fuse; r++) {
         const uint32_t pairs = h_round_pairs_[r];
         if (pairs == 0) continue;
         launch_batch_add(pairs, opt.safe != 0, d_points, rscan_.as<uint32_t>(), nb, r, d_meta);
+        mark(pl);
+      }
+      if (r_fuse < R && h_round_pairs_[r_fuse] > 0) {
+        constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
+        const uint32_t ppw = (uint32_t)T * fused_b_;
+        const uint32_t n_wgs = (h_round_pairs_[r_fuse] + ppw - 1) / ppw;
+        if ((st = wgfirst_.ensure(((size_t)n_wgs + 2) * 4))) return st;
+        hipLaunchKernelGGL(k_wg_first_bucket, dim3((n_wgs + 1 + 255) / 256), dim3(256), 0, stream_,
+                           wgfirst_.as<uint32_t>(), rscan_.as<uint32_t>() + (size_t)r_fuse * ((size_t)nb + 1), nb, ppw,
+                           n_wgs);
+        if constexpr (!TE) {
+          if (opt.safe != 0) {
+            hipLaunchKernelGGL((k_batch_add_fused<F, T, true, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
+                               slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
+                               rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), r_fuse);
+          } else {
+            hipLaunchKernelGGL((k_batch_add_fused<F, T, false, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
+                               slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
+                               rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), r_fuse);
+          }
+        }
         mark(pl);
       }
     }
@@ -976,6 +999,7 @@ class Engine : public IEngine {
   uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 2048u;
   uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 1024u;
   int tail_skip_ = getenv("MSMZ_TAIL_SKIP") ? atoi(getenv("MSMZ_TAIL_SKIP")) : 2;
+  int fuse_tail_ = getenv("MSMZ_FUSE_TAIL") ? atoi(getenv("MSMZ_FUSE_TAIL")) : 0;
   uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
   int fb_cap_ = getenv("MSMZ_FB") ? atoi(getenv("MSMZ_FB")) : 0;
   uint32_t s1_override_ = getenv("MSMZ_S1") ? (uint32_t)atoi(getenv("MSMZ_S1")) : 0u;

@@ -42,7 +42,7 @@
 #define MSMZ_INST_BATCH_FUSED(F, SAFE, PFX)                                                                       \
   PFX template __global__ void k_batch_add_fused<F, MSMZ_BATCH_T, SAFE, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(         \
       uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, MsmMeta*,      \
-      const uint32_t*);
+      const uint32_t*, int);
 
 #define MSMZ_INST_BATCH(F, Fr, PFX)                                                                               \
   MSMZ_INST_BATCH_FUSED(F, true, PFX)                                                                             \

@@ -1068,13 +1068,13 @@ template <class F, int T, bool SAFE, int OCC, int BMAX>
 __global__ void __launch_bounds__(T, OCC) k_batch_add_fused(uint32_t* slots, const uint32_t* points,
                                                             const uint32_t* refs, const uint32_t* off,
                                                             const uint32_t* rscan_all, uint32_t nb, int R,
-                                                            MsmMeta* meta, const uint32_t* wg_first) {
+                                                            MsmMeta* meta, const uint32_t* wg_first, int r_begin) {
   __shared__ int32_t tree[F::N * T];
   __shared__ uint32_t s_loc[BMAX * T];
   __shared__ uint8_t s_kind[BMAX * T];
   const uint32_t g_lo = wg_first[blockIdx.x], g_hi = wg_first[blockIdx.x + 1];   // buckets [g_lo, g_hi)
   if (g_lo >= g_hi) return;
-  for (int r = 0; r < R; r++) {
+  for (int r = r_begin; r < R; r++) {
     const uint32_t* rscan = rscan_all + (size_t)r * ((size_t)nb + 1);
     const uint32_t p_lo = rscan[g_lo], p_hi = rscan[g_hi];
     for (uint32_t base = p_lo; base < p_hi; base += (uint32_t)(T * BMAX)) {
