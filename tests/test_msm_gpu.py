@@ -175,6 +175,36 @@ def test_safe_path_edge_cases(curves):
         assert curve.Parallel.msmProjective(sc, pts, len(points))["result"] == want
 
 
+def test_golden_msm_vectors(curves):
+    """tests/golden/msm_vectors.json: device-generated inputs (same seeds) and every MSM entry point against the
+    committed expected results -- no oracle call at run time"""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msm_vectors.json")) as f:
+        vectors = json.load(f)["vectors"]
+    assert len(vectors) == 16
+    for v in vectors:
+        curve = curves(v["curve"])
+        n = v["n"]
+        pts = curve.Parallel.randomPointsFast(n, v["seed"])
+        sc = curve.Parallel.randomScalars(n, v["seed"])
+        p0 = curve.Affine.toBigints(pts)[0]
+        assert (hex(p0["x"]), hex(p0["y"])) == (v["first_point"]["x"], v["first_point"]["y"])
+        assert hex(curve.Scalar.toBigints(sc)[0]) == v["first_scalar"]
+        want = (v["result"]["x"], v["result"]["y"], v["result"]["isZero"])
+
+        def key(r):
+            return (hex(r["x"]), hex(r["y"]), bool(r.get("isZero", False)))
+
+        if v["curve"] == "ed-on-bls12-377":
+            assert key(curve.Parallel.msm(sc, pts, n)["result"]) == want
+        else:
+            for glv in (0, 1):
+                assert key(curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": glv})["result"]) == want
+                assert key(curve.Parallel.msm(sc, pts, n, False, {"glv": glv})["result"]) == want
+            assert key(curve.Parallel.msmProjective(sc, pts, n)["result"]) == want
+        pts.free(); sc.free()
+
+
 @pytest.mark.parametrize("label", ["bls12-377", "pallas"])
 def test_long_buckets(curves, label):
     """Heavily repeated scalars: a few buckets hold hundreds of (distinct) points, so the pair tree runs many
