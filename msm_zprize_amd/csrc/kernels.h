@@ -7,15 +7,18 @@
 //                        (msm-batched-affine.ts:149,172-200; scalar-glv.ts:105-128)
 //   k_scan_*             exclusive prefix sums: bucket offsets and per-round pair offsets
 //                        (msm-batched-affine.ts:411-435 integrateBucketCounts)
-//   k_scatter            counting-sort scatter of point *indices* into bucket order
+//   k_scatter_coarse,    counting sort of point *indices* into bucket order in two LDS-staged passes (k_scatter is
+//   k_sort_fine          the one-pass atomic fallback)
 //                        (msm-batched-affine.ts:444-490 sortPoints -- which copies 116-byte points;
-//                        here 4-byte references are scattered and points are gathered on first use)
+//                        here 4-byte references are sorted and points are gathered on first use)
 //   k_batch_add          one tree round of batched-affine additions inside all buckets, with a
-//                        workgroup-wide Montgomery batch inversion (product tree in LDS, one field
-//                        inversion per workgroup)
+//                        workgroup-wide Montgomery batch inversion (product tree in LDS, one wave-wide field
+//                        inversion per workgroup, fe_inverse_wave); results in chunk-interleaved slot arrays
 //                        (msm-batched-affine.ts:232-270; curve-affine.ts:376-522; inverse.ts:220-271)
-//   k_reduce_first/next  bucket reduction  sum_l l*B_l  by grouped running sums in XYZZ coordinates
-//                        (msm-batched-affine.ts:544-571 reduceBucketsColumnProjective)
+//   k_reduce_first,      bucket reduction  sum_l l*B_l  by grouped running sums in XYZZ coordinates: first level
+//   k_reduce_quad(16),   from the (partial) bucket sums, upper levels with a quad of lanes per group / per addition
+//   k_reduce_next        (msm-batched-affine.ts:544-571 reduceBucketsColumnProjective)
+//   k_bucket_accumulate  msmBasic path: buckets in XYZZ / extended coordinates (msm-basic.ts:106-128)
 //
 // Bucket numbering: global bucket g = k*L + (l-1) for window k and digit l in [1, L], L = 2^(c-1).
 // Sorted references: ref = point_index | (negate << 31).
@@ -34,7 +37,7 @@ struct MsmMeta {               // small device-resident block of run-time totals
   uint32_t max_bucket;         // largest bucket size
   uint32_t n_entries;          // E = number of non-zero digits = point additions' inputs
   uint32_t error;              // bit 0: zero denominator hit in the unsafe batch add
-  uint32_t pad;
+  uint32_t pad;                // MSMZ_DBG timing-experiment bits (0 in normal operation)
   uint32_t round_pairs[32];    // number of pairs in tree round r
   uint32_t round_base[32];     // first record of round r's result array inside `slots` (prefix sum of round_pairs)
 };
