@@ -788,14 +788,18 @@ class Engine : public IEngine {
     MsmMeta* d_meta = meta_.as<MsmMeta>();
     const int ev_plan0 = pl.ei;
     mark(pl);
-    // chunk offsets: cscan[g] = sum_{g' < g} ceil(size/64)
+    // chunk offsets: cscan[g] = sum_{g' < g} ceil(size / 2^chunk_shift); chunks of 64 entries unless some bucket is
+    // very long (then ~sqrt of it: bounds both the chunk and the number of partial sums one reduction thread adds)
+    int chunk_shift = ACC_CHUNK_SHIFT;
+    while ((1ull << (2 * chunk_shift)) < pl.max_bucket) chunk_shift++;
+    const int scan_mode = 2 | (chunk_shift << 4);
     if ((st = rscan_.ensure(((size_t)nb + 1) * 4))) return st;
     hipLaunchKernelGGL(k_scan_partials, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(),
-                       off_.as<uint32_t>(), nb, 2, nblocks);
+                       off_.as<uint32_t>(), nb, scan_mode, nblocks);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, stream_, partials_.as<uint32_t>(), nblocks,
                        d_meta->round_pairs);
     hipLaunchKernelGGL(k_scan_apply, dim3(nblocks, 1), dim3(SCAN_T), 0, stream_, rscan_.as<uint32_t>(),
-                       partials_.as<uint32_t>(), off_.as<uint32_t>(), nb, 2, nblocks, (size_t)0, (uint32_t*)nullptr);
+                       partials_.as<uint32_t>(), off_.as<uint32_t>(), nb, scan_mode, nblocks, (size_t)0, (uint32_t*)nullptr);
     MSMZ_HIP(hipMemcpyAsync(h_meta_, d_meta, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
     const uint32_t n_chunks = h_meta_->round_pairs[0];
@@ -805,7 +809,7 @@ class Engine : public IEngine {
     if (n_chunks > 0) {
       hipLaunchKernelGGL((k_bucket_accumulate<P>), dim3((n_chunks + 127) / 128), dim3(128), 0, stream_,
                          slots_.as<uint32_t>(), (const uint32_t*)pts.dev, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                         rscan_.as<uint32_t>(), nb, n_chunks);
+                         rscan_.as<uint32_t>(), nb, n_chunks, chunk_shift);
     }
     const int ev_acc_end = pl.ei;
     mark(pl);

@@ -60,7 +60,7 @@
   PFX template __global__ void k_reduce_next<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
                                                 const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t); \
   PFX template __global__ void k_bucket_accumulate<P>(uint32_t*, const uint32_t*, const uint32_t*,               \
-                                                      const uint32_t*, const uint32_t*, uint32_t, uint32_t);
+                                                      const uint32_t*, const uint32_t*, uint32_t, uint32_t, int);
 
 #define MSMZ_INST_REDUCE(F, Fr, PFX)                                                                              \
   PFX template __global__ void k_reduce_first<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \

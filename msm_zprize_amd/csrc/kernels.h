@@ -284,7 +284,10 @@ __device__ __forceinline__ uint32_t scan_value(const uint32_t* in, uint32_t g, u
   if (g >= n) return 0;
   if (mode == 0) return in[g];
   uint32_t s = in[g + 1] - in[g];
-  if (mode == 2) return (s + 63u) >> 6;   // chunks of ACC_CHUNK = 64 entries (msmBasic accumulation)
+  if ((mode & 15) == 2) {                // chunks of 2^(mode >> 4) entries (msmBasic accumulation)
+    const int sh = mode >> 4;
+    return (s + (1u << sh) - 1u) >> sh;
+  }
   uint32_t m = 1u << r;
   return (s + m - 1) >> (r + 1);
 }
@@ -1271,15 +1274,18 @@ struct TePolicy {
 // Bucket accumulation without batch inversion (msm-basic.ts:106-128: addMixed / subMixed into projective
 // or extended buckets).  The sorted reference list of every bucket is cut into chunks of CH entries
 // (cscan = exclusive scan of ceil(size / CH), scan mode 2); one thread folds one chunk into an accumulator.
+// CH = 64 normally; for very long buckets (adversarial scalars) CH ~ sqrt(longest bucket), so that neither a chunk
+// nor the list of a bucket's partial sums (added up by one thread of the first reduction level) gets long.
 #ifndef MSMZ_REDUCE_OCC
 #define MSMZ_REDUCE_OCC 2   // waves per SIMD the register budget of the big reduction kernels is capped for
 #endif
-constexpr int ACC_CHUNK = 64;
+constexpr int ACC_CHUNK_SHIFT = 6;   // normal chunk = 64 entries; the host raises it to ~sqrt(longest bucket)
 
 template <class P>
 __global__ void __launch_bounds__(128) k_bucket_accumulate(uint32_t* partial, const uint32_t* points,
                                                            const uint32_t* refs, const uint32_t* off,
-                                                           const uint32_t* cscan, uint32_t nb, uint32_t n_chunks) {
+                                                           const uint32_t* cscan, uint32_t nb, uint32_t n_chunks,
+                                                           int chunk_shift) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_chunks) return;
   uint32_t lo = 0, hi = nb;   // cscan[lo] <= t < cscan[hi]
@@ -1287,8 +1293,8 @@ __global__ void __launch_bounds__(128) k_bucket_accumulate(uint32_t* partial, co
     uint32_t mid = (lo + hi) >> 1;
     if (cscan[mid] <= t) lo = mid; else hi = mid;
   }
-  const uint32_t start = off[lo] + (t - cscan[lo]) * ACC_CHUNK;
-  const uint32_t end = min(start + ACC_CHUNK, off[lo + 1]);
+  const uint32_t start = off[lo] + ((t - cscan[lo]) << chunk_shift);
+  const uint32_t end = min(start + (1u << chunk_shift), off[lo + 1]);
   typename P::Acc acc, tmp;
   P::zero(acc);
   for (uint32_t p = start; p < end; p++) {

@@ -106,3 +106,32 @@ def test_config5_shard_2e23_per_gpu(mod):
     sc = curve.Parallel.randomScalars(n, 52)
     assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"] == _expected("bls12-377", 51, 52, n)
     curve.close()
+
+
+@pytest.mark.parametrize("label", ["bls12-377", "pallas", "ed-on-bls12-377"])
+def test_equal_scalars_one_long_bucket_per_window(mod, label):
+    """Adversarial input: all 2^16 scalars equal, so every window has ONE bucket holding every point (the
+    same-scalar case of src/bigint/msm.test.ts:47-56 at a size where it stresses the long-bucket handling: many tree
+    rounds on the affine path, sqrt-sized chunks on the projective / twisted-Edwards path).
+    Expected: (s * sum a_i mod q) * G."""
+    import numpy as np
+    c = P.CURVES[label]
+    q = c["order"]
+    n = 1 << 16
+    params = mod.curves.BY_LABEL[label]
+    curve = (mod.Weierstrass if params["kind"] == "weierstrass" else mod.TwistedEdwards).create(params)
+    pts = curve.Parallel.randomPointsFast(n, 31)
+    a_sum = int(sum(int(v) for v in prng.multipliers_np(31, n)))
+    gen = {"x": c["generator"]["x"], "y": c["generator"]["y"], "isZero": False}
+    for s in (q - 2, 0x1234567890ABCDEF1234567890ABCDEF1234567 % q):
+        r = c_oracle.scale(c, s * a_sum % q, gen)
+        want = {"x": r["x"], "y": r["y"], "isZero": bool(r.get("isZero", False))}
+        sc = curve.Parallel.scalarsFromBytes(int(s).to_bytes(32, "little") * n, n)
+        if params["kind"] == "weierstrass":
+            assert _strip(curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"]) == want
+            assert _strip(curve.Parallel.msm(sc, pts, n, False, {"glv": 1})["result"]) == want
+            assert _strip(curve.Parallel.msmProjective(sc, pts, n)["result"]) == want
+        else:
+            assert _strip(curve.Parallel.msm(sc, pts, n)["result"]) == want
+        sc.free()
+    curve.close()
