@@ -162,6 +162,20 @@ def scatter_traffic():
         return None
 
 
+def effective_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box of this pool
+    shows 256 logical CPUs but grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(params, log2n):
     """The oracle's C restatement of src/bigint/msm.ts timed on this host's cores, on a bounded sample
     (2^log2n points of the same distribution).  A reported baseline, not the target."""
@@ -179,15 +193,18 @@ def cpu_baseline(params, log2n):
     from msm_zprize_amd import _native
     _native.check(_native.lib().msmz_download_points(curve._ctx, pts.handle, 0, n, pbuf, None), "download")
     _native.check(_native.lib().msmz_download_scalars(curve._ctx, sc.handle, 0, n, sbuf), "download")
-    threads = min(c_oracle.lib().oracle_num_threads(), os.cpu_count() or 1)
+    threads = min(c_oracle.lib().oracle_num_threads(), effective_cpus())
+    # bigint/msm.ts on one index range has only ~14 windows to run in parallel; shard the input so that
+    # (ranges x windows) covers every core that is reported
+    shards = max(1, threads // 14)
     t0 = time.perf_counter()
-    res, adds = c_oracle.msm_bytes(oparams, sbuf.raw, pbuf.raw, n, None, threads)
+    res, adds = c_oracle.msm_bytes_sharded(oparams, sbuf.raw, pbuf.raw, n, shards, threads)
     dt = time.perf_counter() - t0
     gpu = curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"]
     curve.close()
     return {"value": adds / dt / 1e6, "unit": "Mpoint-adds/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/msm_oracle.c (restated src/bigint/msm.ts) on 2^{log2n} points, {dt:.2f} s, "
-                      f"OpenMP over windows; result {'==' if gpu == res else '!='} GPU result",
+            "sample": f"oracle/msm_oracle.c (restated src/bigint/msm.ts) on 2^{log2n} points in {shards} index ranges, "
+                      f"{dt:.2f} s, OpenMP over ranges x windows; result {'==' if gpu == res else '!='} GPU result",
             "ms_per_msm": dt * 1e3}
 
 

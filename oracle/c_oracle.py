@@ -23,6 +23,10 @@ def lib():
         l.oracle_msm.restype = C.c_int
         l.oracle_msm.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p,
                                  C.c_uint64, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint64)]
+        l.oracle_msm_sharded.restype = C.c_int
+        l.oracle_msm_sharded.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p,
+                                         C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_int,
+                                         C.POINTER(C.c_uint64)]
         l.oracle_scale.restype = C.c_int
         l.oracle_scale.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p,
                                    C.POINTER(C.c_int)]
@@ -52,6 +56,22 @@ def msm_bytes(params, scalars_le32: bytes, points_xy: bytes, n: int, is_inf: byt
     r = {"x": int.from_bytes(out.raw[:fb], "little"), "y": int.from_bytes(out.raw[fb:], "little"), "isZero": inf.value != 0}
     if r["isZero"] and kind == 0:
         r["x"], r["y"] = 0, 1
+    return r, adds.value
+
+
+def msm_bytes_sharded(params, scalars_le32: bytes, points_xy: bytes, n: int, shards: int, threads: int = 0):
+    """msm_bytes on `shards` contiguous index ranges in parallel (bench.py's CPU baseline); returns (point, n_adds)."""
+    kind, p_le, nl, d = _curve_args(params)
+    fb = params["fe_bytes"]
+    out = C.create_string_buffer(2 * fb)
+    inf = C.c_int()
+    adds = C.c_uint64()
+    bits = (params["order"] - 1).bit_length()
+    st = lib().oracle_msm_sharded(kind, p_le, nl, d, bits, scalars_le32, points_xy, None, n, shards, out, C.byref(inf),
+                                  threads, C.byref(adds))
+    if st:
+        raise RuntimeError(f"oracle_msm_sharded failed: {st}")
+    r = {"x": int.from_bytes(out.raw[:fb], "little"), "y": int.from_bytes(out.raw[fb:], "little"), "isZero": inf.value != 0}
     return r, adds.value
 
 

@@ -249,6 +249,68 @@ int oracle_msm(int kind, const uint8_t* p_le, int nlimbs, uint64_t d, int scalar
   return 0;
 }
 
+/* The same algorithm on `shards` contiguous index ranges at once (each range with its own window size
+ * c = log2(range) - 1, its own buckets and its own Horner step), all (range, window) pairs as one pool of OpenMP
+ * tasks, the range results added at the end: MSM(A u B) = MSM(A) + MSM(B).  bigint/msm.ts parallelizes over
+ * nothing; oracle_msm above over its ~14 windows; this form exists so that bench.py's CPU baseline can occupy all
+ * the cores it reports. */
+int oracle_msm_sharded(int kind, const uint8_t* p_le, int nlimbs, uint64_t d, int scalar_bits, const uint8_t* scalars_le32,
+                       const uint8_t* points_xy, const uint8_t* is_inf, uint64_t n, int shards, uint8_t* out_xy,
+                       int* out_is_inf, int threads, uint64_t* n_adds) {
+  if (nlimbs != 4 && nlimbs != 6) return 1;
+  if (shards < 1) shards = 1;
+  if ((uint64_t)shards > n) shards = (int)n;
+  curve_t C; curve_init(&C, kind, p_le, nlimbs, d);
+  int nb = 8 * nlimbs;
+  uint64_t per = (n + shards - 1) / shards;
+  int c = log2ceil(per) - 1; if (c < 1) c = 1;
+  if (c > 24) return 1;
+  int K = (scalar_bits + c - 1) / c;
+  uint64_t L = (uint64_t)1 << c;
+  pt* pts = (pt*)malloc(sizeof(pt) * n);
+  pt* part = (pt*)malloc(sizeof(pt) * (size_t)K * shards);
+  if (!pts || !part) return 2;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)n; i++) load_point(&C, &pts[i], points_xy + (size_t)i * 2 * nb, is_inf ? is_inf[i] : 0);
+  uint64_t adds = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : adds)
+  for (int task = 0; task < K * shards; task++) {
+    const int sh = task / K, k = task % K;
+    const uint64_t i0 = (uint64_t)sh * per, i1 = i0 + per < n ? i0 + per : n;
+    pt* buckets = (pt*)malloc(sizeof(pt) * (L - 1));
+    for (uint64_t l = 0; l < L - 1; l++) c_zero(&C, &buckets[l]);
+    for (uint64_t i = i0; i < i1; i++) {
+      uint32_t l = window(scalars_le32 + 32 * i, k * c, c);
+      if (l == 0) continue;
+      c_add(&C, &buckets[l - 1], &buckets[l - 1], &pts[i]);
+      adds++;
+    }
+    pt running, triangle; c_zero(&C, &running); c_zero(&C, &triangle);
+    for (int64_t l = (int64_t)L - 2; l >= 0; l--) {
+      c_add(&C, &running, &running, &buckets[l]);
+      c_add(&C, &triangle, &triangle, &running);
+    }
+    part[task] = triangle;
+    free(buckets);
+  }
+  pt total; c_zero(&C, &total);
+  for (int sh = 0; sh < shards; sh++) {
+    pt result = part[(size_t)sh * K + K - 1];
+    for (int k = K - 2; k >= 0; k--) {
+      for (int i = 0; i < c; i++) c_double(&C, &result, &result);
+      c_add(&C, &result, &result, &part[(size_t)sh * K + k]);
+    }
+    c_add(&C, &total, &total, &result);
+  }
+  *out_is_inf = store_point(&C, out_xy, &total);
+  if (n_adds) *n_adds = adds;
+  free(pts); free(part);
+  return 0;
+}
+
 /* s * P by MSB-first double-and-add (affine-weierstrass.ts:111-119 / twisted-edwards.ts:129-137) */
 int oracle_scale(int kind, const uint8_t* p_le, int nlimbs, uint64_t d, const uint8_t* scalar_le32, const uint8_t* point_xy,
                  int is_inf, uint8_t* out_xy, int* out_is_inf) {

@@ -151,3 +151,17 @@ def test_c_oracle_known_answers_and_edge_cases():
     k = P.KAT_ED377_POINT
     te = P.ED_ON_BLS12_377
     assert c_oracle.msm(te, [2, te["order"] - 1], [k, k]) == {"x": k["x"], "y": k["y"], "isZero": False}
+
+
+def test_sharded_c_oracle_equals_plain():
+    """oracle_msm_sharded (bench.py's CPU baseline) == oracle_msm: MSM(A u B) = MSM(A) + MSM(B)"""
+    from oracle import prng
+    for c in (P.BLS12_377, P.ED_ON_BLS12_377):
+        q, fb, n = c["order"], c["fe_bytes"], 700
+        gen = {"x": c["generator"]["x"], "y": c["generator"]["y"]}
+        pts = [c_oracle.scale(c, prng.point_multiplier(5, i), gen) for i in range(n)]
+        sb = b"".join(int(prng.scalar(5, i, q)).to_bytes(32, "little") for i in range(n))
+        pb = b"".join(int(p["x"]).to_bytes(fb, "little") + int(p["y"]).to_bytes(fb, "little") for p in pts)
+        want = c_oracle.msm_bytes(c, sb, pb, n, None, 4)[0]
+        for shards in (1, 2, 5, 700, 900):
+            assert c_oracle.msm_bytes_sharded(c, sb, pb, n, shards, 4)[0] == want, (c["label"], shards)
