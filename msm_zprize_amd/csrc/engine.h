@@ -1001,7 +1001,7 @@ class Engine : public IEngine {
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
   uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 2048u;
-  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 1024u;
+  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 512u;
   int tail_skip_ = getenv("MSMZ_TAIL_SKIP") ? atoi(getenv("MSMZ_TAIL_SKIP")) : 2;
   int fuse_tail_ = getenv("MSMZ_FUSE_TAIL") ? atoi(getenv("MSMZ_FUSE_TAIL")) : 0;
   uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;

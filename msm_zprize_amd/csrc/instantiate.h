@@ -30,7 +30,7 @@
 #define MSMZ_TE_FIELDS(X) MSMZ_T3(X)
 
 #ifndef MSMZ_BATCH_T
-#define MSMZ_BATCH_T 128
+#define MSMZ_BATCH_T 256
 #endif
 #ifndef MSMZ_BATCH_OCC
 #define MSMZ_BATCH_OCC 4
