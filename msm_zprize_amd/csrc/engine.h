@@ -790,7 +790,7 @@ class Engine : public IEngine {
     mark(pl);
     // chunk offsets: cscan[g] = sum_{g' < g} ceil(size / 2^chunk_shift); chunks of 64 entries unless some bucket is
     // very long (then ~sqrt of it: bounds both the chunk and the number of partial sums one reduction thread adds)
-    int chunk_shift = ACC_CHUNK_SHIFT;
+    int chunk_shift = chunk_shift_override_ > 0 ? chunk_shift_override_ : ACC_CHUNK_SHIFT;
     while ((1ull << (2 * chunk_shift)) < pl.max_bucket) chunk_shift++;
     const int scan_mode = 2 | (chunk_shift << 4);
     if ((st = rscan_.ensure(((size_t)nb + 1) * 4))) return st;
@@ -1004,6 +1004,7 @@ class Engine : public IEngine {
   uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 512u;
   int tail_skip_ = getenv("MSMZ_TAIL_SKIP") ? atoi(getenv("MSMZ_TAIL_SKIP")) : 2;
   int fuse_tail_ = getenv("MSMZ_FUSE_TAIL") ? atoi(getenv("MSMZ_FUSE_TAIL")) : 0;
+  int chunk_shift_override_ = getenv("MSMZ_CHUNK_SHIFT") ? atoi(getenv("MSMZ_CHUNK_SHIFT")) : 0;
   uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
   int fb_cap_ = getenv("MSMZ_FB") ? atoi(getenv("MSMZ_FB")) : 0;
   uint32_t s1_override_ = getenv("MSMZ_S1") ? (uint32_t)atoi(getenv("MSMZ_S1")) : 0u;
