@@ -8,8 +8,8 @@
  * See INTEGRATION.md for the binding a maintainer would add.
  *
  * Conventions: every function returns an int status (0 = MSMZ_OK; msmz_strerror() explains the
- * rest); no C++ types cross the boundary; the caller owns all host buffers; a context is bound to
- * one GPU and is not thread-safe (use one context per thread / per GPU); there is no CPU fallback --
+ * rest); no C++ types cross the boundary; the caller owns all host buffers; a context drives the
+ * GPU(s) it was created for and is not thread-safe (one caller at a time per context); there is no CPU fallback --
  * creating a context without a usable HIP device fails.
  *
  * Wire formats (same as the reference's byte route, parallel.ts:97-133, 209-249):
@@ -85,13 +85,21 @@ typedef struct msmz_log {
 
 typedef struct msmz_ctx msmz_ctx;
 
-/* device_ids / n_devices: the GPU(s) this context drives.  n_devices must be 1 in this round
- * (multi-GPU runs use one process + one context per GPU; partial sums are combined with
- * msmz_point_add).  Replaces startThreads(n) (parallel.ts:291-315). */
+/* device_ids / n_devices: the GPU(s) this context drives, 1 <= n_devices <= MSMZ_MAX_DEVICES (0 = "CPU backend":
+ * refused with MSMZ_ERR_NO_DEVICE).  Replaces startThreads(n) (parallel.ts:291-315, threads.ts:132-359): with
+ * n_devices > 1 the context owns one engine + HIP stream + host thread per device, every uploaded / generated set is
+ * split over the devices in contiguous blocks of 2^16 entries dealt round-robin (so the first n entries of a set are a
+ * prefix on every device), msmz_msm runs the whole pipeline on each device's share concurrently and adds the partial
+ * sums on the host (no inter-GPU traffic).  The same device id may be listed more than once
+ * (used to rehearse the scheduler on one GPU).  The other route to multi-GPU -- one process and one single-device
+ * context per GPU, partial sums combined with msmz_point_add -- is what bench.py --gpus N uses. */
+#define MSMZ_MAX_DEVICES 8
 int msmz_create(msmz_ctx** ctx, int curve_id, const int* device_ids, int n_devices);
 void msmz_destroy(msmz_ctx* ctx);            /* stopThreads() + frees every handle */
 const char* msmz_strerror(int status);
 int msmz_curve_fe_bytes(int curve_id);       /* 48 or 32; -1 for an unknown curve */
+int msmz_ctx_fe_bytes(const msmz_ctx* ctx);  /* fe_bytes of the context's curve; -1 for a null context */
+int msmz_ctx_n_devices(const msmz_ctx* ctx); /* number of engines (GPUs) the context drives */
 
 /* Point sets live on the GPU across MSMs, like the reference keeps them in wasm memory
  * (scripts/msm-weierstrass.ts:19-35).  pointsFromBytes (parallel.ts:97-112 / 209-232). */

@@ -24,7 +24,8 @@ export interface MsmCurve {
   Projective: { toAffine(scratch: unknown, affPtr: unknown, result: BigintPoint): BigintPoint; toBigint(r: BigintPoint): BigintPoint };
   pointAdd(a: BigintPoint, b: BigintPoint): BigintPoint; close(): void;
 }
-export function startThreads(n?: number, deviceId?: number): Promise<number>;
+/** n = number of GPUs a curve context drives (inputs split over them); deviceId = first GPU or an explicit list */
+export function startThreads(n?: number, deviceId?: number | number[]): Promise<number | number[]>;
 export function stopThreads(): Promise<void>;
 export const Weierstraß: { create(params: CurveParams): Promise<MsmCurve> };
 export const Weierstrass: { create(params: CurveParams): Promise<MsmCurve> };

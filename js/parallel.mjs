@@ -26,18 +26,26 @@ function native() {
   return addon;
 }
 
-let device = null;
+let devices = null;
 
-/** parallel.ts:291-315.  The "threads" are the GPU's wavefronts: this selects the device. */
+/** parallel.ts:291-315.  The reference spawns n-1 workers that share one MSM; here the workers are GPUs: a curve
+ * created after startThreads(n) drives GPUs first..first+n-1 (inputs split over them, partial sums added on the
+ * host: msmz_create with n_devices = n).  Without n: one GPU, LOCAL_RANK or 0.  `deviceId` may also be an array
+ * of ids. */
 export async function startThreads(n, deviceId) {
-  device = deviceId !== undefined ? deviceId : Number(process.env.LOCAL_RANK || 0);
+  if (Array.isArray(deviceId)) devices = deviceId.map(Number);
+  else {
+    const first = deviceId !== undefined ? Number(deviceId) : n === undefined || n === 1 ? Number(process.env.LOCAL_RANK || 0) : 0;
+    devices = Array.from({ length: n || 1 }, (_, i) => first + i);
+  }
+  if (devices.length < 1 || devices.length > 8) throw Error(`startThreads: 1..8 GPUs, got ${devices.length}`);
   native();
-  return device;
+  return devices.length === 1 ? devices[0] : devices;
 }
 
 /** parallel.ts:317-320 */
 export async function stopThreads() {
-  device = null;
+  devices = null;
 }
 
 function bytesToBigint(buf, off, len) {
@@ -72,9 +80,9 @@ class DeviceArray extends Array {
 
 function createCurve(params, kind) {
   if (params.kind !== kind) throw Error(`${params.label} is not a ${kind} curve`);
-  if (device === null) device = Number(process.env.LOCAL_RANK || 0);
+  if (devices === null) devices = [Number(process.env.LOCAL_RANK || 0)];
   const N = native();
-  const ctx = N.create(params.curveId, device);
+  const ctx = N.create(params.curveId, devices.length === 1 ? devices[0] : devices);
   const fb = params.feBytes;
   const te = kind === "twisted-edwards";
   const curve = { params, _ctx: ctx };
@@ -116,12 +124,14 @@ function createCurve(params, kind) {
     },
     /** parallel.ts:97-112: x||y little-endian canonical */
     async pointsFromBytes(bytes, n, isInf) {
-      n = n === undefined ? bytes.length / (2 * fb) : n;
+      n = n === undefined ? Math.floor(bytes.length / (2 * fb)) : n;
+      if (!(n > 0) || bytes.length < 2 * fb * n || (isInf && isInf.length < n)) throw Error(`pointsFromBytes: ${bytes.length} bytes for ${n} points`);
       return DeviceArray.make(curve, N.uploadPoints(ctx, Buffer.from(bytes), isInf ? Buffer.from(isInf) : null, n), n, "points");
     },
     /** parallel.ts:114-133: 32 bytes little-endian per scalar */
     async scalarsFromBytes(bytes, n) {
-      n = n === undefined ? bytes.length / 32 : n;
+      n = n === undefined ? Math.floor(bytes.length / 32) : n;
+      if (!(n > 0) || bytes.length < 32 * n) throw Error(`scalarsFromBytes: ${bytes.length} bytes for ${n} scalars`);
       return DeviceArray.make(curve, N.uploadScalars(ctx, Buffer.from(bytes), n), n, "scalars");
     },
     /** msm-batched-affine.ts:74-328 with safe additions */

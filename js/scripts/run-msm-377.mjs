@@ -1,5 +1,5 @@
 // Mirror of the reference's scripts/run-msm-377.ts + scripts/msm-weierstrass.ts:
-//   node js/scripts/run-msm-377.mjs <n> [--evaluate] [--glv 0|1] [--json]
+//   node js/scripts/run-msm-377.mjs <n> [--evaluate] [--glv 0|1] [--gpus G] [--json]
 // --evaluate reproduces the reference's protocol (msm-weierstrass.ts:22-48): warm-up MSM at 2^15,
 // 15 runs with fresh scalars, first 5 dropped, median +- sample standard deviation.
 import { Weierstraß, startThreads, stopThreads } from "../parallel.mjs";
@@ -22,13 +22,14 @@ async function main() {
   const json = args.includes("--json");
   const glv = args.includes("--glv") ? Number(args[args.indexOf("--glv") + 1]) : 1;
   const N = 1 << n;
-  await startThreads();
+  const gpus = args.includes("--gpus") ? Number(args[args.indexOf("--gpus") + 1]) : undefined;
+  await startThreads(gpus);
   const Curve = await Weierstraß.create(curveParams);
   const { Parallel } = Curve;
   let [pointPtr] = await Parallel.randomPointsFast(N, { seed: 1n });
   if (doEvaluate) {
     let [scalarPtr] = await Parallel.randomScalars(N, { seed: 2n });
-    await Parallel.msmUnsafe(scalarPtr, pointPtr, Math.min(N, 1 << 15), true, { glv: glv && N <= 1 << 15 ? 1 : 0 });
+    await Parallel.msmUnsafe(scalarPtr, pointPtr, Math.min(N, 1 << 15), true, { glv });   // warm-up (msm-weierstrass.ts:24)
     const times = [];
     for (let i = 0; i < 15; i++) {
       let [s] = await Parallel.randomScalars(N, { seed: BigInt(100 + i) });

@@ -31,6 +31,8 @@ EXPORTS = {
     "msmz_destroy": (None, [C.c_void_p]),
     "msmz_strerror": (C.c_char_p, [C.c_int]),
     "msmz_curve_fe_bytes": (C.c_int, [C.c_int]),
+    "msmz_ctx_fe_bytes": (C.c_int, [C.c_void_p]),
+    "msmz_ctx_n_devices": (C.c_int, [C.c_void_p]),
     "msmz_upload_points": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "msmz_upload_scalars": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "msmz_random_points": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),

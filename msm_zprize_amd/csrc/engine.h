@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "gen_kernels.h"
 #include "host64.h"
+#include "multi.h"
 
 namespace msmz {
 
@@ -63,20 +64,6 @@ struct Handle {
   void* dev;
 };
 
-class IEngine {
- public:
-  virtual ~IEngine() {}
-  virtual int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h) = 0;
-  virtual int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h) = 0;
-  virtual int random_points(uint64_t n, uint64_t seed, uint64_t* h) = 0;
-  virtual int random_scalars(uint64_t n, uint64_t seed, uint64_t* h) = 0;
-  virtual int download_points(uint64_t h, uint64_t first, uint64_t count, uint8_t* xy, uint8_t* inf) = 0;
-  virtual int download_scalars(uint64_t h, uint64_t first, uint64_t count, uint8_t* s) = 0;
-  virtual int free_handle(uint64_t h) = 0;
-  virtual int msm(uint64_t ph, const uint8_t* host_scalars, uint64_t sh, uint64_t n, const msmz_opts* o, uint8_t* out,
-                  int* out_inf, msmz_log* log) = 0;
-};
-
 static inline int ceil_log2_u64(uint64_t x) {
   int r = 0;
   while (((uint64_t)1 << r) < x) r++;
@@ -120,7 +107,7 @@ class Engine : public IEngine {
   ~Engine() override {
     (void)hipSetDevice(device_);
     for (auto& kv : handles_) (void)hipFree(kv.second.dev);
-    for (DevBuf* b : {&wgfirst_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+    for (DevBuf* b : {&packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
                       &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
       b->release();
     if (h_meta_) (void)hipHostFree(h_meta_);
@@ -132,7 +119,7 @@ class Engine : public IEngine {
 
   // ------------------------------------------------------------------------------------------ data
   int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h) override {
-    if (!xy || !h || n == 0 || n >= (1ull << 30)) return MSMZ_ERR_ARG;
+    if (!xy || !h || n == 0 || n >= (1ull << (Cfg::HAS_ENDO ? 29 : 30))) return MSMZ_ERR_ARG;   // record indices (incl. endomorphism images) fit 30 bits
     MSMZ_HIP(hipSetDevice(device_));
     // range check on the host: coordinates must be canonical (< p)
     for (uint64_t i = 0; i < 2 * n; i++) {
@@ -180,8 +167,8 @@ class Engine : public IEngine {
     return MSMZ_OK;
   }
 
-  int random_points(uint64_t n, uint64_t seed, uint64_t* h) override {
-    if (!h || n == 0 || n >= (1ull << 30)) return MSMZ_ERR_ARG;
+  int random_points(uint64_t n, uint64_t seed, const GenMap& map, uint64_t* h) override {
+    if (!h || n == 0 || n >= (1ull << (Cfg::HAS_ENDO ? 29 : 30))) return MSMZ_ERR_ARG;   // record indices (incl. endomorphism images) fit 30 bits
     MSMZ_HIP(hipSetDevice(device_));
     int st = ensure_gen_table();
     if (st) return st;
@@ -190,10 +177,10 @@ class Engine : public IEngine {
     MSMZ_HIP(hipMalloc(&dev, (size_t)n * PW_WORDS * 4 * (endo ? 2 : 1)));
     if constexpr (TE) {
       hipLaunchKernelGGL((k_te_gen_points<F>), dim3((n + 127) / 128), dim3(128), 0, stream_, (uint32_t*)dev,
-                         gen_table_.as<uint32_t>(), (uint32_t)n, seed);
+                         gen_table_.as<uint32_t>(), (uint32_t)n, seed, map);
     } else {
       hipLaunchKernelGGL((k_gen_points<F>), dim3((n + 127) / 128), dim3(128), 0, stream_, (uint32_t*)dev,
-                         gen_table_.as<uint32_t>(), (uint32_t)n, seed, endo ? 1 : 0);
+                         gen_table_.as<uint32_t>(), (uint32_t)n, seed, endo ? 1 : 0, map);
     }
     MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipStreamSynchronize(stream_));
@@ -202,13 +189,13 @@ class Engine : public IEngine {
     return MSMZ_OK;
   }
 
-  int random_scalars(uint64_t n, uint64_t seed, uint64_t* h) override {
+  int random_scalars(uint64_t n, uint64_t seed, const GenMap& map, uint64_t* h) override {
     if (!h || n == 0) return MSMZ_ERR_ARG;
     MSMZ_HIP(hipSetDevice(device_));
     void* dev = nullptr;
     MSMZ_HIP(hipMalloc(&dev, n * 32));
     hipLaunchKernelGGL((k_gen_scalars<Fr>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)dev, (uint32_t)n,
-                       seed);
+                       seed, map);
     MSMZ_HIP(hipGetLastError());
     MSMZ_HIP(hipStreamSynchronize(stream_));
     *h = next_handle_++;
@@ -302,6 +289,7 @@ class Engine : public IEngine {
     int Keff, spread;           // bucket windows incl. the top window's 2^spread sub-windows
     bool glv, timing;
     uint32_t max_bucket = 0, n_entries = 0;
+    uint32_t endo_delta = 0;    // GLV over a prefix of a set: half-1 entry i reads point record pts_n + i = (n + i) + endo_delta
     int ei = 0;                 // next event slot
     int ev_coarse = -1, ev_sort_end = -1;
   };
@@ -410,7 +398,7 @@ class Engine : public IEngine {
     pl.nb = (uint32_t)nb64;
     pl.nblocks = (pl.nb + SCAN_TILE - 1) / SCAN_TILE;
     pl.timing = opt.timing != 0;
-    (void)pts_n;
+    pl.endo_delta = glv ? pts_n - pl.n : 0u;
     return MSMZ_OK;
   }
 
@@ -427,7 +415,6 @@ class Engine : public IEngine {
     if ((st = partials_.ensure((size_t)32 * nblocks * 4))) return st;
     MsmMeta* d_meta = meta_.as<MsmMeta>();
     MSMZ_HIP(hipMemsetAsync(d_meta, 0, sizeof(MsmMeta), stream_));
-    if (dbg_) MSMZ_HIP(hipMemcpyAsync(&d_meta->pad, &dbg_, 4, hipMemcpyHostToDevice, stream_));
     // two-level LDS-staged sort when the packed (fine | negate | index) word fits; else per-entry atomics
     // packed word = fine bucket bits | negate | index: the narrower the index, the more fine bits fit, the
     // fewer (and longer) coarse runs the scatter writes
@@ -480,14 +467,13 @@ class Engine : public IEngine {
       mark(pl);  // 3
       {
         const size_t lds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!fine_attr_set_) {   // the attribute is per device: set once per engine
           MSMZ_HIP(hipFuncSetAttribute((const void*)k_sort_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          attr_set = true;
+          fine_attr_set_ = true;
         }
         hipLaunchKernelGGL(k_sort_fine, dim3(nbins), dim3(FINE_T), lds, stream_, refs_.as<uint32_t>(),
                            off_.as<uint32_t>(), &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb,
-                           nbins, idx_bits);
+                           nbins, idx_bits, pl.glv ? n : 0xffffffffu, pl.endo_delta);
       }
     } else {
       MSMZ_HIP(hipMemsetAsync(counts_.p, 0, ((size_t)nb + 1) * 4, stream_));
@@ -513,7 +499,8 @@ class Engine : public IEngine {
       {
         dim3 grid((M + 256 * 4 - 1) / (256 * 4), K);
         hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, stream_, refs_.as<uint32_t>(), cursor_.as<uint32_t>(),
-                           off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c, pl.spread);
+                           off_.as<uint32_t>(), digits_.as<uint32_t>(), M, c, pl.spread, pl.glv ? n : 0xffffffffu,
+                           pl.endo_delta);
       }
       pl.ev_coarse = pl.ei;
       mark(pl);  // 3
@@ -534,26 +521,21 @@ class Engine : public IEngine {
     constexpr int AW = P::ACC_WORDS;
     int st;
     while (n_in > 1) {
-      uint32_t S = no_quad_ ? (n_in <= 8 ? (1u << ceil_log2_u64(n_in)) : 4) : 4;   // quads handle short tails too
+      const uint32_t S = 4;   // quads handle short tails too
       uint32_t g2 = (n_in + S - 1) / S;
       int nxt = cur ^ 1;
       if ((st = red_[nxt * 2].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
       if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
       uint32_t total = pl.Keff * g2;
-      if (S == 4 && !no_quad_ && total <= quad16_max_groups_) {
+      if (total <= quad16_max_groups_) {
         // small level: latency-bound, one DPP quad per addition
         hipLaunchKernelGGL((k_reduce_quad16<P>), dim3((total * 16 + 63) / 64), dim3(64), 0, stream_,
                            red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
                            red_[cur * 2].as<uint32_t>(), red_[cur * 2 + 1].as<uint32_t>(), n_in, g2, total);
-      } else if (S == 4 && !no_quad_) {
+      } else {
         hipLaunchKernelGGL((k_reduce_quad<P>), dim3((total * 4 + 63) / 64), dim3(64), 0, stream_,
                            red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
                            red_[cur * 2].as<uint32_t>(), red_[cur * 2 + 1].as<uint32_t>(), n_in, g2, total);
-      } else {
-        hipLaunchKernelGGL((k_reduce_next<P>), dim3((total + 127) / 128), dim3(128), 0, stream_,
-                           red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
-                           red_[cur * 2].as<uint32_t>(), red_[cur * 2 + 1].as<uint32_t>(), (const uint32_t*)nullptr,
-                           n_in, S, g2, total, pl.L);
       }
       n_in = g2;
       cur = nxt;
@@ -628,10 +610,6 @@ class Engine : public IEngine {
     log->stage_ms[MSMZ_ST_ACCUMULATE] = elapsed(ev_plan1, ev_acc_end);
     log->stage_ms[MSMZ_ST_REDUCE] = elapsed(ev_acc_end, ev_red_end);
     int prev = ev_plan1, rr = 0;
-    if (log_fused_) {   // all rounds ran in one launch: its time is reported as round 0
-      log->batch_add_ms[0] = elapsed(ev_plan1, round_ev0);
-      return;
-    }
     for (int r = 0; r < R && r < 32; r++) {
       if (h_round_pairs_[r] == 0) continue;
       int e = round_ev0 + rr;
@@ -647,8 +625,6 @@ class Engine : public IEngine {
                              uint8_t* out, int* out_inf, msmz_log* log) {
     const bool glv = opt.glv != 0;
     if (glv && (!Fr::HAS_GLV || !pts.has_endo)) return MSMZ_ERR_UNSUPPORTED;
-    // GLV addresses the endomorphism images at index handle.n + i, so the MSM must cover the whole set
-    if (glv && n64 != pts.n) return MSMZ_ERR_UNSUPPORTED;
     Plan pl;
     int st = make_plan(pl, n64, glv, opt, (uint32_t)pts.n);
     if (st) return st;
@@ -693,59 +669,11 @@ class Engine : public IEngine {
     const uint32_t* d_points = (const uint32_t*)pts.dev;
     const int round_ev0 = pl.ei;
     for (int r = 0; r < R; r++) n_pairs += h_round_pairs_[r];
-    // Balanced buckets (the normal case): all rounds in ONE launch, each workgroup owning a range of buckets.
-    // Very large buckets (adversarial inputs, e.g. many equal scalars): one launch per round, pairs split evenly.
-    const bool fused = !no_fused_ && R > 0 && pl.max_bucket <= fused_max_bucket_;
-    log_fused_ = fused;
-    if (fused) {
-      constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
-      const uint32_t ppw = (uint32_t)T * fused_b_;
-      const uint32_t n_wgs = (h_round_pairs_[0] + ppw - 1) / ppw;
-      if ((st = wgfirst_.ensure(((size_t)n_wgs + 2) * 4))) return st;
-      hipLaunchKernelGGL(k_wg_first_bucket, dim3((n_wgs + 1 + 255) / 256), dim3(256), 0, stream_,
-                         wgfirst_.as<uint32_t>(), rscan_.as<uint32_t>(), nb, ppw, n_wgs);
-      if constexpr (!TE) {
-        if (opt.safe != 0) {
-          hipLaunchKernelGGL((k_batch_add_fused<F, T, true, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
-                             slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), 0);
-        } else {
-          hipLaunchKernelGGL((k_batch_add_fused<F, T, false, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
-                             slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                             rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), 0);
-        }
-      }
+    for (int r = 0; r < R; r++) {
+      const uint32_t pairs = h_round_pairs_[r];
+      if (pairs == 0) continue;
+      launch_batch_add(pairs, opt.safe != 0, d_points, rscan_.as<uint32_t>(), nb, r, d_meta);
       mark(pl);
-    } else {
-      // experiment (MSMZ_FUSE_TAIL=n): the last n rounds in one launch, each workgroup owning a range of buckets
-      const int r_fuse = (fuse_tail_ >= 2 && R > fuse_tail_) ? R - fuse_tail_ : R;
-      for (int r = 0; r < r_fuse; r++) {
-        const uint32_t pairs = h_round_pairs_[r];
-        if (pairs == 0) continue;
-        launch_batch_add(pairs, opt.safe != 0, d_points, rscan_.as<uint32_t>(), nb, r, d_meta);
-        mark(pl);
-      }
-      if (r_fuse < R && h_round_pairs_[r_fuse] > 0) {
-        constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
-        const uint32_t ppw = (uint32_t)T * fused_b_;
-        const uint32_t n_wgs = (h_round_pairs_[r_fuse] + ppw - 1) / ppw;
-        if ((st = wgfirst_.ensure(((size_t)n_wgs + 2) * 4))) return st;
-        hipLaunchKernelGGL(k_wg_first_bucket, dim3((n_wgs + 1 + 255) / 256), dim3(256), 0, stream_,
-                           wgfirst_.as<uint32_t>(), rscan_.as<uint32_t>() + (size_t)r_fuse * ((size_t)nb + 1), nb, ppw,
-                           n_wgs);
-        if constexpr (!TE) {
-          if (opt.safe != 0) {
-            hipLaunchKernelGGL((k_batch_add_fused<F, T, true, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
-                               slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                               rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), r_fuse);
-          } else {
-            hipLaunchKernelGGL((k_batch_add_fused<F, T, false, OCC, BMAX>), dim3(n_wgs), dim3(T), 0, stream_,
-                               slots_.as<uint32_t>(), d_points, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                               rscan_.as<uint32_t>(), nb, R, d_meta, wgfirst_.as<uint32_t>(), r_fuse);
-          }
-        }
-        mark(pl);
-      }
     }
     const int ev_acc_end = pl.ei;
     mark(pl);
@@ -845,7 +773,6 @@ class Engine : public IEngine {
     finalize_weierstrass(pl, out, out_inf);
     float host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     memset(h_round_pairs_, 0, sizeof(h_round_pairs_));
-    log_fused_ = false;
     fill_log(log, pl, 0, pl.n_entries, basic_ev_[0], basic_ev_[1], basic_ev_[2], basic_ev_[3], 0, host_ms);
     return MSMZ_OK;
   }
@@ -878,7 +805,6 @@ class Engine : public IEngine {
     *out_inf = 0;
     float host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     memset(h_round_pairs_, 0, sizeof(h_round_pairs_));
-    log_fused_ = false;
     fill_log(log, pl, 0, pl.n_entries, basic_ev_[0], basic_ev_[1], basic_ev_[2], basic_ev_[3], 0, host_ms);
     return MSMZ_OK;
   }
@@ -1000,28 +926,27 @@ class Engine : public IEngine {
   hipEvent_t ev_[kMaxEvents] = {};
   std::map<uint64_t, Handle> handles_;
   uint64_t next_handle_ = 1;
-  uint32_t coarse_wgs_ = getenv("MSMZ_COARSE_WGS") ? (uint32_t)atoi(getenv("MSMZ_COARSE_WGS")) : 2048u;
-  uint32_t batch_min_wgs_ = getenv("MSMZ_BATCH_WGS") ? (uint32_t)atoi(getenv("MSMZ_BATCH_WGS")) : 512u;
-  int tail_skip_ = getenv("MSMZ_TAIL_SKIP") ? atoi(getenv("MSMZ_TAIL_SKIP")) : 2;
-  int fuse_tail_ = getenv("MSMZ_FUSE_TAIL") ? atoi(getenv("MSMZ_FUSE_TAIL")) : 0;
-  int chunk_shift_override_ = getenv("MSMZ_CHUNK_SHIFT") ? atoi(getenv("MSMZ_CHUNK_SHIFT")) : 0;
-  uint32_t dbg_ = getenv("MSMZ_DBG") ? (uint32_t)atoi(getenv("MSMZ_DBG")) : 0u;
-  int fb_cap_ = getenv("MSMZ_FB") ? atoi(getenv("MSMZ_FB")) : 0;
-  uint32_t s1_override_ = getenv("MSMZ_S1") ? (uint32_t)atoi(getenv("MSMZ_S1")) : 0u;
-  // single-launch variant of the tree rounds: measured 1.8x slower than one launch per round (late rounds leave
-  // most of each workgroup idle while it still pays a serial inversion per round) -> opt-in only
-  bool no_fused_ = getenv("MSMZ_FUSED") == nullptr;
-  uint32_t fused_max_bucket_ = getenv("MSMZ_FUSED_MAXB") ? (uint32_t)atoi(getenv("MSMZ_FUSED_MAXB")) : 2048u;
-  uint32_t fused_b_ = getenv("MSMZ_FUSED_B") ? (uint32_t)atoi(getenv("MSMZ_FUSED_B")) : 16u;
-  bool no_quad_ = getenv("MSMZ_NO_QUAD") != nullptr;
-  uint32_t quad16_max_groups_ = getenv("MSMZ_QUAD16") ? (uint32_t)atoi(getenv("MSMZ_QUAD16")) : 8192u;   // levels with at most this many groups use k_reduce_quad16
+  // Tuning knobs.  A release build uses the constants; a development build (-DMSMZ_DEV, tools/build_variant.sh)
+  // reads MSMZ_* environment variables when the context is created.  None of them changes a result.
+#ifdef MSMZ_DEV
+  static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+  static int env_int(const char*, int dflt) { return dflt; }
+#endif
+  uint32_t coarse_wgs_ = (uint32_t)env_int("MSMZ_COARSE_WGS", 2048);
+  uint32_t batch_min_wgs_ = (uint32_t)env_int("MSMZ_BATCH_WGS", 512);
+  int tail_skip_ = env_int("MSMZ_TAIL_SKIP", 2);
+  int chunk_shift_override_ = env_int("MSMZ_CHUNK_SHIFT", 0);
+  int fb_cap_ = env_int("MSMZ_FB", 0);
+  uint32_t s1_override_ = (uint32_t)env_int("MSMZ_S1", 0);
+  uint32_t quad16_max_groups_ = (uint32_t)env_int("MSMZ_QUAD16", 8192);   // levels with at most this many groups use k_reduce_quad16
   Host64<F> host64_;
-  bool no_spread_ = getenv("MSMZ_NO_SPREAD") != nullptr;
-  bool no_window_model_ = getenv("MSMZ_NO_WINDOW_MODEL") != nullptr;
-  bool force_atomic_sort_ = getenv("MSMZ_ATOMIC_SORT") != nullptr;
-  int batch_b_override_ = getenv("MSMZ_BATCH_B") ? atoi(getenv("MSMZ_BATCH_B")) : 0;
-  DevBuf wgfirst_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
-  bool log_fused_ = false;
+  bool no_spread_ = env_int("MSMZ_NO_SPREAD", 0) != 0;
+  bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
+  bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
+  int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
+  bool fine_attr_set_ = false;
+  DevBuf packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};
   int basic_ev_[4] = {};

@@ -17,14 +17,14 @@
 // the same limb schedule idea as the reference's w=29 wasm code (multiply-montgomery.ts:47
 // `nSafeSteps`), and the CIOS variant is kept in fp_cios.h for the A/B measurement.
 //
-// Bounds (checked in tests/test_fp_model.py with the integer model of this file):
+// Bounds (checked in tests/test_fp_host.py, which compiles this file for the host):
 //   mul/sqr inputs : |value| < 2^5 * p (2^3 * p for the 255-bit fields) and the limb magnitudes
 //                    A, B of the two operands satisfy  N*A*B + N*2^(2W) < 2^63
 //   mul/sqr output : value in (-1.5p, 0.5p), limbs 0..N-2 in [0, 2^W), top limb small signed.
 #pragma once
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MSMZ_HD __host__ __device__ __forceinline__
 #else
 #define MSMZ_HD inline

@@ -11,12 +11,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include "multi.h"
 
 namespace msmz {
 
 constexpr int GEN_BITS = 13;
 constexpr int GEN_TABLE = 1 << GEN_BITS;
 constexpr int GEN_WINDOWS = 5;   // 5 * 13 = 65 >= 64 bits
+
+// local index on one device of a multi-GPU context -> global (seeded) index; identity for a single device
+MSMZ_HD uint64_t gen_global_index(uint32_t local, const GenMap& m) {
+  const uint64_t blk = (uint64_t)local >> m.blk_shift;
+  return ((blk * m.nshards + m.shard) << m.blk_shift) | ((uint64_t)local & ((1ull << m.blk_shift) - 1));
+}
 
 MSMZ_HD uint64_t splitmix64(uint64_t seed, uint64_t index) {
   uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
@@ -62,11 +69,11 @@ __global__ void __launch_bounds__(128) k_gen_table(uint32_t* table, const uint32
 
 template <class F>
 __global__ void __launch_bounds__(128) k_gen_points(uint32_t* out, const uint32_t* table, uint32_t n, uint64_t seed,
-                                                    int endo) {
+                                                    int endo, GenMap map) {
   constexpr int RW = 2 * F::NW;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint64_t a = splitmix64(seed, i);
+  uint64_t a = splitmix64(seed, gen_global_index(i, map));
   Xyzz<F> acc, tmp;
   xyzz_set_inf(acc);
 #pragma unroll 1
@@ -94,16 +101,17 @@ __global__ void __launch_bounds__(128) k_gen_points(uint32_t* out, const uint32_
 }
 
 template <class Fr>
-__global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* out, uint32_t n, uint64_t seed) {
+__global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* out, uint32_t n, uint64_t seed, GenMap map) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const uint64_t gi = gen_global_index(i, map);
   constexpr int TOP_BITS = Fr::BITS - 224;            // bits kept in the top 32-bit word
   constexpr uint32_t TOP_MASK = TOP_BITS >= 32 ? 0xffffffffu : ((1u << TOP_BITS) - 1u);
   uint32_t w[8];
   for (uint32_t attempt = 0; attempt < 64; attempt++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      uint64_t v = splitmix64(seed ^ 0x5ca1a75ull, ((uint64_t)i * 64 + attempt) * 4 + j);
+      uint64_t v = splitmix64(seed ^ 0x5ca1a75ull, (gi * 64 + attempt) * 4 + j);
       w[2 * j] = (uint32_t)v;
       w[2 * j + 1] = (uint32_t)(v >> 32);
     }
@@ -210,11 +218,12 @@ __global__ void __launch_bounds__(128) k_te_gen_table(uint32_t* table, const uin
 }
 
 template <class F>
-__global__ void __launch_bounds__(128) k_te_gen_points(uint32_t* out, const uint32_t* table, uint32_t n, uint64_t seed) {
+__global__ void __launch_bounds__(128) k_te_gen_points(uint32_t* out, const uint32_t* table, uint32_t n, uint64_t seed,
+                                                       GenMap map) {
   constexpr int RW = 2 * F::NW;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint64_t a = splitmix64(seed, i);
+  uint64_t a = splitmix64(seed, gen_global_index(i, map));
   TeExt<F> acc, tmp, q;
   te_set_zero(acc);
 #pragma unroll 1

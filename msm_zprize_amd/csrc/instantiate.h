@@ -39,14 +39,7 @@
 #define MSMZ_BATCH_BMAX 16
 #endif
 
-#define MSMZ_INST_BATCH_FUSED(F, SAFE, PFX)                                                                       \
-  PFX template __global__ void k_batch_add_fused<F, MSMZ_BATCH_T, SAFE, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(         \
-      uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, MsmMeta*,      \
-      const uint32_t*, int);
-
 #define MSMZ_INST_BATCH(F, Fr, PFX)                                                                               \
-  MSMZ_INST_BATCH_FUSED(F, true, PFX)                                                                             \
-  MSMZ_INST_BATCH_FUSED(F, false, PFX)                                                                            \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, true, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(              \
       uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, int, MsmMeta*); \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, false, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(             \
@@ -72,7 +65,7 @@
 
 #define MSMZ_INST_SCALAR(Fr, PFX)                                                                                 \
   PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int, int); \
-  PFX template __global__ void k_gen_scalars<Fr>(uint32_t*, uint32_t, uint64_t);
+  PFX template __global__ void k_gen_scalars<Fr>(uint32_t*, uint32_t, uint64_t, GenMap);
 
 #define MSMZ_INST_MISC(F, Fr, PFX)                                                                                \
   PFX template __global__ void k_points_to_mont<F>(uint32_t*, const uint32_t*, const uint8_t*, uint32_t, int);    \
@@ -87,11 +80,11 @@
 
 #define MSMZ_INST_GEN(F, Fr, PFX)                                                \
   PFX template __global__ void k_gen_table<F>(uint32_t*, const uint32_t*);       \
-  PFX template __global__ void k_gen_points<F>(uint32_t*, const uint32_t*, uint32_t, uint64_t, int);
+  PFX template __global__ void k_gen_points<F>(uint32_t*, const uint32_t*, uint32_t, uint64_t, int, GenMap);
 
 #define MSMZ_INST_GEN_TE(F, Fr, PFX)                                             \
   PFX template __global__ void k_te_gen_table<F>(uint32_t*, const uint32_t*);    \
-  PFX template __global__ void k_te_gen_points<F>(uint32_t*, const uint32_t*, uint32_t, uint64_t);
+  PFX template __global__ void k_te_gen_points<F>(uint32_t*, const uint32_t*, uint32_t, uint64_t, GenMap);
 
 #define MSMZ_EXTERN extern
 #define MSMZ_DEFINE

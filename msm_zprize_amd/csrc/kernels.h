@@ -37,7 +37,7 @@ struct MsmMeta {               // small device-resident block of run-time totals
   uint32_t max_bucket;         // largest bucket size
   uint32_t n_entries;          // E = number of non-zero digits = point additions' inputs
   uint32_t error;              // bit 0: zero denominator hit in the unsafe batch add
-  uint32_t pad;                // MSMZ_DBG timing-experiment bits (0 in normal operation)
+  uint32_t pad;
   uint32_t round_pairs[32];    // number of pairs in tree round r
   uint32_t round_base[32];     // first record of round r's result array inside `slots` (prefix sum of round_pairs)
 };
@@ -374,8 +374,12 @@ static __global__ void __launch_bounds__(SCAN_T) k_scan_apply(uint32_t* out, con
 // refs[off[g] + (arrival order within bucket g)] = i | negate<<31  for every non-zero digit.
 // (This is the HBM-bound "bucket scatter": algorithmic bytes = 4 B digit read + 4 B reference write
 // per entry)
+// `n_half` / `endo_delta`: with GLV the entry index i >= n_half is the endomorphism half of point i - n_half; its
+// record sits at index i + endo_delta of the point set (the images follow the whole set, which may be larger than
+// the prefix this MSM covers: msm-batched-affine.ts:74-97 takes any N <= allocated).
 static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t* cursor, const uint32_t* off,
-                                                 const uint32_t* digits, uint32_t M, int c, int spread) {
+                                                 const uint32_t* digits, uint32_t M, int c, int spread,
+                                                 uint32_t n_half, uint32_t endo_delta) {
   constexpr int ITEMS = 4;
   const uint32_t L = 1u << (c - 1);
   const uint32_t k = blockIdx.y;
@@ -391,12 +395,12 @@ static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t
     const uint32_t kw = (k + 1 == gridDim.y) ? k + (i & ((1u << spread) - 1u)) : k;
     uint32_t g = kw * L + (l - 1);
     uint32_t pos = off[g] + atomicAdd(&cursor[g], 1u);
-    refs[pos] = i | (d & REF_NEG);
+    refs[pos] = (i >= n_half ? i + endo_delta : i) | (d & REF_NEG);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ two-level sort
-// Replacement for {global-atomic histogram, k_scatter} when M <= 2^23: a most-significant-digit radix
+// Replacement for {global-atomic histogram, k_scatter} when M <= 2^24: a most-significant-digit radix
 // partition of the (bucket, reference) pairs in two LDS-staged passes, so that no pass issues one
 // global atomic per entry and every global store instruction writes contiguous runs.
 //
@@ -533,7 +537,8 @@ constexpr int FINE_STAGE = 38400;   // entries staged in LDS: 150 KB + 8 KB of c
 
 static __global__ void __launch_bounds__(FINE_T) k_sort_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
                                                              const uint32_t* packed, const uint32_t* bin_base, int fb,
-                                                             uint32_t n_bins, int idx_bits) {
+                                                             uint32_t n_bins, int idx_bits, uint32_t n_half,
+                                                             uint32_t endo_delta) {
   extern __shared__ uint32_t s_dyn[];
   uint32_t* s_cnt = s_dyn;                                  // [1 << FINE_MAX_BITS] counts, then running cursors
   uint32_t* s_stage = s_dyn + (1 << FINE_MAX_BITS);          // [FINE_STAGE]
@@ -583,7 +588,9 @@ static __global__ void __launch_bounds__(FINE_T) k_sort_fine(uint32_t* refs, uin
   for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) {
     const uint32_t v = packed[p];
     const uint32_t pos = atomicAdd(&s_cnt[v >> (idx_bits + 1)], 1u);
-    const uint32_t ref = (v & imask) | (((v >> idx_bits) & 1u) << 31);
+    uint32_t idx = v & imask;
+    if (idx >= n_half) idx += endo_delta;   // endomorphism half: record index in the point set
+    const uint32_t ref = idx | (((v >> idx_bits) & 1u) << 31);
     if (staged) s_stage[pos] = ref; else refs[begin + pos] = ref;
   }
   if (staged) {
@@ -802,7 +809,6 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
   constexpr int NW = F::NW;
   constexpr int RW = 2 * NW;
   const uint32_t out_base = meta->round_base[r];
-  const uint32_t dbg = meta->pad;   // timing experiments only (MSMZ_DBG): 1 = no inversion, 2 = no tree
   const uint32_t m = 1u << r;
   const uint32_t* rscan = rscan_all + (size_t)r * ((size_t)nb + 1);
 
@@ -842,15 +848,10 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
       const uint32_t start = off[g], size = off[g + 1] - start;
       const uint32_t a = (t - rscan[g]) * 2 * m, b = a + m;
       const uint32_t locA = element_location(g, start, size, a, r, refs, rscan_all, nb, meta);
-      uint32_t locB = element_location(g, start, size, b, r, refs, rscan_all, nb, meta);
-      uint32_t locA_dbg = locA;
-      if ((dbg & 4u) && r == 0) {   // timing experiment: sequential instead of gathered operands (2^20 inputs)
-        locA_dbg = LOC_ORIG | ((2u * t) & 0xfffffu);
-        locB = LOC_ORIG | ((2u * t + 1u) & 0xfffffu);
-      }
+      const uint32_t locB = element_location(g, start, size, b, r, refs, rscan_all, nb, meta);
       uint32_t negA, negB;
       int csA, csB;
-      const uint32_t* recA = location_record<F>(locA_dbg, slots, points, negA, csA);
+      const uint32_t* recA = location_record<F>(locA, slots, points, negA, csA);
       const uint32_t* recB = location_record<F>(locB, slots, points, negB, csB);
       Affine<F> p1, p2;
       bool infA = load_affine<F>(p1, recA, negA, csA);
@@ -907,7 +908,6 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
 
   // ---------------------------------------------------------------- workgroup-wide inversion of the T products
   Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
-  if (!(dbg & 2u)) {
   {
     Fe<F> partner, node;
 #pragma unroll
@@ -941,8 +941,7 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
     Fe<F> root, inv;
 #pragma unroll
     for (int j = 0; j < N; j++) root.l[j] = tree[j * T + lvl_off];
-    bool ok = true;
-    if (dbg & 1u) inv = root; else ok = fe_inverse_wave(inv, root);
+    const bool ok = fe_inverse_wave(inv, root);
     if (threadIdx.x == 0) {
       if (!ok) atomicOr(&meta->error, 1u);
 #pragma unroll
@@ -980,9 +979,6 @@ __device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t*
       ninv.l[j] = tree[j * T + (threadIdx.x >> 1)];
     }
     fe_mul(run, ninv, partner);
-  }
-  } else {
-    run = prefix;
   }
 
   // ---------------------------------------------------------------- backward pass
@@ -1045,55 +1041,6 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   __shared__ uint8_t s_kind[BMAX * T];
   batch_add_chunk<F, T, SAFE, BMAX>(slots, points, refs, off, rscan_all, nb, r, B, meta,
                                     blockIdx.x * (uint32_t)(T * B), meta->round_pairs[r], 0u, nb - 1, tree, s_loc, s_kind);
-}
-
-// ALL tree rounds in one launch: the pair tree of a bucket only depends on that bucket, so workgroup w owns the
-// buckets [wg_first[w], wg_first[w+1]) (cut so that every workgroup gets ~pairs_per_wg round-0 pairs) and runs
-// rounds 0 .. R-1 on them back to back.  No grid-wide barrier between rounds: while one workgroup sits in its
-// serial inversion the others on the CU compute, and a round's results are re-read by the same workgroup.
-// Between rounds the workgroup's stores must be visible to its own loads: barrier + agent-scope fence
-// (the CU's vector L1 may hold the [x1 | z] record that the result overwrote).
-static __global__ void __launch_bounds__(256) k_wg_first_bucket(uint32_t* wg_first, const uint32_t* rscan0, uint32_t nb,
-                                                                uint32_t pairs_per_wg, uint32_t n_wgs) {
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w > n_wgs) return;
-  uint32_t g = nb;
-  if (w < n_wgs) {
-    const uint64_t target = (uint64_t)w * pairs_per_wg;   // smallest g with rscan0[g] >= target
-    uint32_t lo = 0, hi = nb;
-    while (lo < hi) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (rscan0[mid] >= target) hi = mid; else lo = mid + 1;
-    }
-    g = lo;
-  }
-  wg_first[w] = g;
-}
-
-template <class F, int T, bool SAFE, int OCC, int BMAX>
-__global__ void __launch_bounds__(T, OCC) k_batch_add_fused(uint32_t* slots, const uint32_t* points,
-                                                            const uint32_t* refs, const uint32_t* off,
-                                                            const uint32_t* rscan_all, uint32_t nb, int R,
-                                                            MsmMeta* meta, const uint32_t* wg_first, int r_begin) {
-  __shared__ int32_t tree[F::N * T];
-  __shared__ uint32_t s_loc[BMAX * T];
-  __shared__ uint8_t s_kind[BMAX * T];
-  const uint32_t g_lo = wg_first[blockIdx.x], g_hi = wg_first[blockIdx.x + 1];   // buckets [g_lo, g_hi)
-  if (g_lo >= g_hi) return;
-  for (int r = r_begin; r < R; r++) {
-    const uint32_t* rscan = rscan_all + (size_t)r * ((size_t)nb + 1);
-    const uint32_t p_lo = rscan[g_lo], p_hi = rscan[g_hi];
-    for (uint32_t base = p_lo; base < p_hi; base += (uint32_t)(T * BMAX)) {
-      const uint32_t left = p_hi - base;
-      int B = (int)((left + T - 1) / T);
-      if (B > BMAX) B = BMAX;
-      batch_add_chunk<F, T, SAFE, BMAX>(slots, points, refs, off, rscan_all, nb, r, B, meta, base, p_hi, g_lo, g_hi - 1,
-                                        tree, s_loc, s_kind);
-      __syncthreads();   // s_loc / s_kind / tree are reused by the next batch
-    }
-    __threadfence();
-    __syncthreads();
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ 4-lane point addition

@@ -50,6 +50,7 @@ using namespace msmz;
 struct msmz_ctx {
   int curve_id;
   IEngine* engine;
+  int n_devices;
 };
 
 template <class F>
@@ -131,32 +132,58 @@ int msmz_curve_fe_bytes(int curve_id) {
   }
 }
 
+int msmz_ctx_fe_bytes(const msmz_ctx* c) { return c ? msmz_curve_fe_bytes(c->curve_id) : -1; }
+int msmz_ctx_n_devices(const msmz_ctx* c) { return c ? c->n_devices : -1; }
+
+static IEngine* make_engine(int curve_id, int device, int* st) {
+  IEngine* eng = nullptr;
+  *st = MSMZ_ERR_UNSUPPORTED;
+  auto make = [&](auto* e) {
+    *st = e->init();
+    eng = e;
+  };
+  switch (curve_id) {
+    case MSMZ_BLS12_377_G1: make(new Engine<CfgBls377>(device)); break;
+    case MSMZ_PALLAS: make(new Engine<CfgPallas>(device)); break;
+    case MSMZ_BLS12_381_G1: make(new Engine<CfgBls381>(device)); break;
+    case MSMZ_ED_ON_BLS12_377: make(new Engine<CfgEd377>(device)); break;
+    default: break;
+  }
+  if (*st != MSMZ_OK) {
+    delete eng;
+    eng = nullptr;
+  }
+  return eng;
+}
+
 int msmz_create(msmz_ctx** out, int curve_id, const int* device_ids, int n_devices) {
   if (!out) return MSMZ_ERR_ARG;
   *out = nullptr;
   if (msmz_curve_fe_bytes(curve_id) < 0) return MSMZ_ERR_ARG;
-  if (n_devices != 1 || !device_ids) return n_devices == 0 ? MSMZ_ERR_NO_DEVICE : MSMZ_ERR_ARG;
+  if (n_devices == 0) return MSMZ_ERR_NO_DEVICE;   // there is no CPU backend
+  if (n_devices < 0 || n_devices > MSMZ_MAX_DEVICES || !device_ids) return MSMZ_ERR_ARG;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MSMZ_ERR_NO_DEVICE;
-  if (device_ids[0] < 0 || device_ids[0] >= count) return MSMZ_ERR_ARG;
-  IEngine* eng = nullptr;
-  int st = MSMZ_ERR_UNSUPPORTED;
-  auto make = [&](auto* e) {
-    st = e->init();
-    eng = e;
-  };
-  switch (curve_id) {
-    case MSMZ_BLS12_377_G1: make(new Engine<CfgBls377>(device_ids[0])); break;
-    case MSMZ_PALLAS: make(new Engine<CfgPallas>(device_ids[0])); break;
-    case MSMZ_BLS12_381_G1: make(new Engine<CfgBls381>(device_ids[0])); break;
-    case MSMZ_ED_ON_BLS12_377: make(new Engine<CfgEd377>(device_ids[0])); break;
-    default: break;
+  for (int i = 0; i < n_devices; i++)
+    if (device_ids[i] < 0 || device_ids[i] >= count) return MSMZ_ERR_ARG;
+  int st = MSMZ_OK;
+  if (n_devices == 1) {
+    IEngine* eng = make_engine(curve_id, device_ids[0], &st);
+    if (!eng) return st;
+    *out = new msmz_ctx{curve_id, eng, 1};
+    return MSMZ_OK;
   }
-  if (st != MSMZ_OK) {
-    delete eng;
-    return st;
+  // one engine (own HIP stream, own buffers) per listed device; the same id may be listed more than once
+  std::vector<IEngine*> engines;
+  for (int i = 0; i < n_devices; i++) {
+    IEngine* eng = make_engine(curve_id, device_ids[i], &st);
+    if (!eng) {
+      for (IEngine* e : engines) delete e;
+      return st;
+    }
+    engines.push_back(eng);
   }
-  *out = new msmz_ctx{curve_id, eng};
+  *out = new msmz_ctx{curve_id, new MultiEngine(curve_id, msmz_curve_fe_bytes(curve_id), engines), n_devices};
   return MSMZ_OK;
 }
 
@@ -173,10 +200,10 @@ int msmz_upload_scalars(msmz_ctx* c, const uint8_t* s, uint64_t n, uint64_t* h) 
   return c ? c->engine->upload_scalars(s, n, h) : MSMZ_ERR_ARG;
 }
 int msmz_random_points(msmz_ctx* c, uint64_t n, uint64_t seed, uint64_t* h) {
-  return c ? c->engine->random_points(n, seed, h) : MSMZ_ERR_ARG;
+  return c ? c->engine->random_points(n, seed, GenMap{}, h) : MSMZ_ERR_ARG;
 }
 int msmz_random_scalars(msmz_ctx* c, uint64_t n, uint64_t seed, uint64_t* h) {
-  return c ? c->engine->random_scalars(n, seed, h) : MSMZ_ERR_ARG;
+  return c ? c->engine->random_scalars(n, seed, GenMap{}, h) : MSMZ_ERR_ARG;
 }
 int msmz_download_points(msmz_ctx* c, uint64_t h, uint64_t first, uint64_t count, uint8_t* xy, uint8_t* inf) {
   return c ? c->engine->download_points(h, first, count, xy, inf) : MSMZ_ERR_ARG;

@@ -19,23 +19,33 @@ import ctypes as C
 from . import _native
 from ._native import MsmzLog, MsmzOpts, check, lib
 
-_state = {"device": None}
+_state = {"devices": None}
+
+MAX_DEVICES = 8
 
 
-def startThreads(n=None, device=None):
-    """parallel.ts:291-315.  The reference spawns n-1 workers; here the "threads" are the GPU's
-    wavefronts, so this only selects the device (default: LOCAL_RANK or 0) and checks it exists."""
+def startThreads(n=None, device=None, devices=None):
+    """parallel.ts:291-315.  The reference spawns n-1 workers that share one MSM; here the workers are GPUs:
+    `n` = number of GPUs a curve context drives (devices 0..n-1; every input set is split over them and the
+    partial sums are added on the host -- msmz_create with n_devices = n).  `device` picks one GPU (default:
+    LOCAL_RANK or 0, the one-process-per-GPU launch of bench.py); `devices` lists ids explicitly (an id may
+    repeat: several engines on one GPU, used to rehearse the scheduler)."""
     import os
-    if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0"))
-    _state["device"] = int(device)
+    if devices is None:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if n in (None, 1) else 0
+        devices = [int(device) + i for i in range(int(n) if n else 1)]
+    devices = [int(d) for d in devices]
+    if not 1 <= len(devices) <= MAX_DEVICES:
+        raise ValueError(f"startThreads: 1..{MAX_DEVICES} devices, got {len(devices)}")
+    _state["devices"] = devices
     lib()  # fail early if the HIP library is not built
-    return _state["device"]
+    return devices[0] if len(devices) == 1 else devices
 
 
 def stopThreads():
     """parallel.ts:317-320."""
-    _state["device"] = None
+    _state["devices"] = None
 
 
 class DeviceArray:
@@ -112,8 +122,10 @@ class _Parallel:
         """parallel.ts:97-112: x||y little-endian canonical, 2*fe_bytes per point."""
         fb = self._c.fe_bytes
         n = len(data) // (2 * fb) if n is None else n
-        if len(data) < 2 * fb * n:
-            raise ValueError("pointsFromBytes: buffer too short")
+        if n <= 0 or len(data) < 2 * fb * n:
+            raise ValueError(f"pointsFromBytes: {len(data)} bytes for {n} points of {2 * fb} bytes")
+        if is_inf is not None and len(is_inf) < n:
+            raise ValueError(f"pointsFromBytes: {len(is_inf)} infinity flags for {n} points")
         h = C.c_uint64()
         check(lib().msmz_upload_points(self._c._ctx, bytes(data), None if is_inf is None else bytes(is_inf), n,
                                        C.byref(h)), "msmz_upload_points")
@@ -122,6 +134,8 @@ class _Parallel:
     def scalarsFromBytes(self, data, n=None):
         """parallel.ts:114-133: 32 bytes little-endian per scalar."""
         n = len(data) // 32 if n is None else n
+        if n <= 0 or len(data) < 32 * n:
+            raise ValueError(f"scalarsFromBytes: {len(data)} bytes for {n} scalars of 32 bytes")
         h = C.c_uint64()
         check(lib().msmz_upload_scalars(self._c._ctx, bytes(data), n, C.byref(h)), "msmz_upload_scalars")
         return DeviceArray(self._c, h.value, n, "scalars")
@@ -150,6 +164,10 @@ class _Parallel:
         out = C.create_string_buffer(2 * fb)
         inf = C.c_int()
         log = MsmzLog()
+        if N <= 0 or N > len(points):
+            raise ValueError(f"msm: N = {N} but the point set holds {len(points)}")
+        if N > (len(scalars) if isinstance(scalars, DeviceArray) else len(scalars) // 32):
+            raise ValueError(f"msm: N = {N} but fewer scalars were given")
         if isinstance(scalars, DeviceArray):
             st = lib().msmz_msm_resident(self._c._ctx, points.handle, scalars.handle, N, C.byref(opts), out,
                                          C.byref(inf), C.byref(log))
@@ -194,15 +212,16 @@ class _Curve:
     def __init__(self, params, kind):
         if params["kind"] != kind:
             raise ValueError(f"{params['label']} is not a {kind} curve")
-        if _state["device"] is None:
+        if _state["devices"] is None:
             startThreads()
         self.params = params
         self.kind = kind
         self.fe_bytes = params["fe_bytes"]
         self.default_glv = 1 if kind == "weierstrass" else 0
         ctx = C.c_void_p()
-        dev = (C.c_int * 1)(_state["device"])
-        check(lib().msmz_create(C.byref(ctx), params["curve_id"], dev, 1), "msmz_create")
+        devs = _state["devices"]
+        self.devices = list(devs)
+        check(lib().msmz_create(C.byref(ctx), params["curve_id"], (C.c_int * len(devs))(*devs), len(devs)), "msmz_create")
         self._ctx = ctx
         self.Scalar = _Scalar(self)
         self.Affine = _Affine(self)

@@ -19,6 +19,23 @@ def shard_range(n_total, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+BLOCK_SHIFT = 16
+
+
+def block_shard_count(n, g, G, shift=BLOCK_SHIFT):
+    """entries of the first n that live on device g of a G-device context (csrc/multi.h shard_count): blocks of
+    2^shift consecutive entries are dealt round-robin, so a prefix of the set is a prefix on every device"""
+    blk = 1 << shift
+    full, rem = divmod(n, blk * G)
+    return full * blk + min(max(rem - g * blk, 0), blk)
+
+
+def block_local_index(i, G, shift=BLOCK_SHIFT):
+    """global entry index -> (device, local index) inside a multi-device context"""
+    b = i >> shift
+    return b % G, ((b // G) << shift) | (i & ((1 << shift) - 1))
+
+
 def encode_point(params, p):
     fb = params["fe_bytes"]
     return int(p["x"]).to_bytes(fb, "little") + int(p["y"]).to_bytes(fb, "little") + \

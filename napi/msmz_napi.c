@@ -64,15 +64,30 @@ static void ctx_finalize(napi_env env, void* data, void* hint) {
   free(slot);
 }
 
-/* create(curveId, deviceId) -> ctx */
+/* create(curveId, deviceId | [deviceIds]) -> ctx   (an array = one engine per listed GPU, startThreads(n)) */
 static napi_value Create(napi_env env, napi_callback_info info) {
   size_t argc = 2; napi_value argv[2];
   NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  int32_t curve = 0, dev = 0;
+  int32_t curve = 0, devs[MSMZ_MAX_DEVICES] = {0};
+  uint32_t ndev = 1;
   NAPI_CALL(env, napi_get_value_int32(env, argv[0], &curve));
-  if (argc > 1) NAPI_CALL(env, napi_get_value_int32(env, argv[1], &dev));
+  if (argc > 1) {
+    bool is_arr = false;
+    NAPI_CALL(env, napi_is_array(env, argv[1], &is_arr));
+    if (is_arr) {
+      NAPI_CALL(env, napi_get_array_length(env, argv[1], &ndev));
+      if (ndev < 1 || ndev > MSMZ_MAX_DEVICES) return throw_status(env, MSMZ_ERR_ARG, "msmz_create");
+      for (uint32_t i = 0; i < ndev; i++) {
+        napi_value v;
+        NAPI_CALL(env, napi_get_element(env, argv[1], i, &v));
+        NAPI_CALL(env, napi_get_value_int32(env, v, &devs[i]));
+      }
+    } else {
+      NAPI_CALL(env, napi_get_value_int32(env, argv[1], &devs[0]));
+    }
+  }
   msmz_ctx* ctx = NULL;
-  int st = msmz_create(&ctx, curve, &dev, 1);
+  int st = msmz_create(&ctx, curve, devs, (int)ndev);
   if (st) return throw_status(env, st, "msmz_create");
   msmz_ctx** slot = (msmz_ctx**)malloc(sizeof(*slot));
   *slot = ctx;
@@ -110,6 +125,11 @@ static napi_value UploadPoints(napi_env env, napi_callback_info info) {
   napi_is_buffer(env, argv[2], &isbuf);
   if (isbuf) NAPI_CALL(env, napi_get_buffer_info(env, argv[2], &inf, &inflen));
   uint64_t n; if (!get_u64(env, argv[3], &n)) return throw_status(env, MSMZ_ERR_ARG, "uploadPoints");
+  {
+    int fbc = msmz_ctx_fe_bytes(ctx);   /* buffers must cover n records: 2 * fe_bytes each (+ one flag byte) */
+    if (fbc <= 0 || n == 0 || xylen / (2 * (size_t)fbc) < n || (inf != NULL && inflen < n))
+      return throw_status(env, MSMZ_ERR_ARG, "uploadPoints");
+  }
   uint64_t h = 0;
   int st = msmz_upload_points(ctx, (const uint8_t*)xy, (const uint8_t*)inf, n, &h);
   if (st) return throw_status(env, st, "msmz_upload_points");

@@ -50,6 +50,13 @@ def test_no_cpu_fallback(lib):
     assert lib.msmz_create(ctypes.byref(ctx), 0, dev, 1) == 2
     assert lib.msmz_create(ctypes.byref(ctx), 0, dev, 0) == 2
     assert lib.msmz_create(ctypes.byref(ctx), 99, dev, 1) == 1
+    # a multi-device context (startThreads(n), parallel.ts:291-315) is accepted by the ABI: without GPUs it is
+    # NO_DEVICE like the single-device one, not ARG; more than MSMZ_MAX_DEVICES ids is an argument error
+    dev2 = (ctypes.c_int * 2)(0, 1)
+    assert lib.msmz_create(ctypes.byref(ctx), 0, dev2, 2) == 2
+    dev9 = (ctypes.c_int * 9)(*range(9))
+    assert lib.msmz_create(ctypes.byref(ctx), 0, dev9, 9) == 1
+    assert lib.msmz_ctx_n_devices(None) == -1 and lib.msmz_ctx_fe_bytes(None) == -1
     import msm_zprize_amd as m
     with pytest.raises(Exception):
         m.Weierstrass.create(m.curves.bls12377Params)
@@ -63,3 +70,44 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".js", ".cc")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_host_layer_validates_buffer_lengths():
+    """a short host buffer must raise before the native library reads past its end"""
+    from msm_zprize_amd import parallel
+
+    class FakeCurve:
+        fe_bytes = 48
+        default_glv = 1
+        kind = "weierstrass"
+        _ctx = None
+
+    par = parallel._Parallel(FakeCurve())
+    with pytest.raises(ValueError):
+        par.pointsFromBytes(b"\0" * 95, 1)
+    with pytest.raises(ValueError):
+        par.pointsFromBytes(b"\0" * 96 * 4, 4, is_inf=b"\0" * 3)
+    with pytest.raises(ValueError):
+        par.scalarsFromBytes(b"\0" * 63, 2)
+    pts = parallel.DeviceArray(FakeCurve(), 1, 4, "points")
+    with pytest.raises(ValueError):
+        par.msmUnsafe(b"\0" * (32 * 3), pts, 4)
+    with pytest.raises(ValueError):
+        par.msmUnsafe(b"\0" * (32 * 8), pts, 5)
+
+
+def test_shard_block_split_is_a_prefix_partition():
+    """msm_zprize_amd/csrc/multi.h: blocks of 2^16 entries dealt round-robin; the first n entries of a set are a
+    prefix of every device's local array and the local counts add up to n (python restatement of shard_count)"""
+    from msm_zprize_amd.sharding import block_shard_count, block_local_index
+    for G in (1, 2, 3, 8):
+        for n in (1, 65535, 65536, 65537, 3 * 65536 + 17, 1 << 20, (1 << 23) + 5):
+            counts = [block_shard_count(n, g, G) for g in range(G)]
+            assert sum(counts) == n
+            for i in (0, n - 1, n // 2, min(n - 1, 65536 * G)):
+                g, li = block_local_index(i, G)
+                assert li < counts[g]
+                # prefix property: the entry just past n on the same device (if any) has a local index >= counts[g]
+            for g in range(G):
+                nxt = [j for j in range(n, n + 65536 * G + 1, 4099) if block_local_index(j, G)[0] == g]
+                assert all(block_local_index(j, G)[1] >= counts[g] for j in nxt)

@@ -148,13 +148,16 @@ def test_known_answer_submission_ed377(curves):
     assert (r["x"], r["y"]) == (k["x"], k["y"])
 
 
-def test_safe_path_edge_cases(curves):
-    """batchAddNew semantics (curve-affine.ts:412-447): infinity inputs, P + P, P + (-P), zero scalars"""
-    curve = curves("bls12-377")
-    c = P.BLS12_377
+@pytest.mark.parametrize("label", WEIER)
+def test_safe_path_edge_cases(curves, label):
+    """batchAddNew semantics (curve-affine.ts:412-447): infinity inputs, P + P, P + (-P), zero scalars -- on every
+    Weierstrass curve (different limb counts / fe_is_zero margins)"""
+    curve = curves(label)
+    c = P.CURVES[label]
     q = c["order"]
-    A = B.AffineWeierstrass(c)
-    pt = dict(P.KAT_BLS12_377_POINT, isZero=False)
+    g = c["generator"]
+    pt = dict(P.KAT_BLS12_377_POINT, isZero=False) if label == "bls12-377" else \
+        _strip(c_oracle.scale(c, 0xDEADBEEF12345, {"x": g["x"], "y": g["y"], "isZero": False}))
     neg = {"x": pt["x"], "y": c["modulus"] - pt["y"], "isZero": False}
     inf = {"x": 0, "y": 0, "isZero": True}
     cases = [
@@ -166,7 +169,7 @@ def test_safe_path_edge_cases(curves):
         ([pt, neg, pt], [q - 1, q - 1, 1]),
     ]
     for points, scalars in cases:
-        want = _oracle("bls12-377", scalars, points)
+        want = _oracle(label, scalars, points)
         pts = curve.Parallel.pointsFromBigints(points)
         sc = curve.Parallel.scalarsFromBigints(scalars)
         for glv in (0, 1):
@@ -253,3 +256,76 @@ def test_range_errors(curves):
         curve.Parallel.scalarsFromBigints([q])
     with pytest.raises(nat.MsmzError):
         curve.Parallel.pointsFromBigints([{"x": p, "y": 1}])
+
+
+@pytest.mark.parametrize("label", WEIER)
+def test_glv_over_a_prefix_of_a_point_set(curves, label):
+    """msm(scalars, points, N) with N < allocated (msm-batched-affine.ts:74-97; the warm-up of
+    scripts/msm-weierstrass.ts:24 is exactly this): the endomorphism images sit behind the WHOLE set"""
+    curve = curves(label)
+    n_set = 1500
+    pts = curve.Parallel.randomPointsFast(n_set, 909)
+    sc = curve.Parallel.randomScalars(n_set, 910)
+    scalars, points = curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts)
+    for n in (1, 7, 300, 1024, 1499):
+        want = _oracle(label, scalars[:n], points[:n])
+        for glv in (0, 1):
+            assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": glv})["result"] == want, (n, glv)
+            assert curve.Parallel.msm(sc, pts, n, False, {"glv": glv, "c": 6})["result"] == want, (n, glv)
+        assert curve.Parallel.msmProjective(sc, pts, n)["result"] == want
+    pts.free(); sc.free()
+
+
+@pytest.mark.parametrize("label", ["bls12-377", "ed-on-bls12-377"])
+def test_multi_engine_context_on_one_gpu(label):
+    """msmz_create with n_devices > 1 (startThreads(n), parallel.ts:291-315): here three engines, all on GPU 0 --
+    the scheduler, the block split of uploads / generators / prefixes and the host-side fold are the same code that
+    drives several GPUs.  Inputs must equal the single-engine ones (generators are functions of the GLOBAL index)
+    and every MSM must equal the oracle."""
+    import msm_zprize_amd as m
+    import msm_zprize_amd._native as nat
+    params = m.curves.BY_LABEL[label]
+    make = (m.Weierstrass if params["kind"] == "weierstrass" else m.TwistedEdwards).create
+    m.startThreads()
+    single = make(params)
+    m.startThreads(devices=[0, 0, 0])
+    multi = make(params)
+    m.startThreads()
+    assert nat.lib().msmz_ctx_n_devices(multi._ctx) == 3 and nat.lib().msmz_ctx_n_devices(single._ctx) == 1
+    n_set = 3 * 65536 + 1000      # every engine holds a full block and the last block is ragged
+    seed = 4711
+    pts1, sc1 = single.Parallel.randomPointsFast(n_set, seed), single.Parallel.randomScalars(n_set, seed)
+    ptsm, scm = multi.Parallel.randomPointsFast(n_set, seed), multi.Parallel.randomScalars(n_set, seed)
+    for first, count in ((0, 50), (65530, 12), (2 * 65536 - 3, 65536 + 9), (n_set - 40, 40)):
+        assert multi.Affine.toBigints(ptsm, first, count) == single.Affine.toBigints(pts1, first, count)
+        assert multi.Scalar.toBigints(scm, first, count) == single.Scalar.toBigints(sc1, first, count)
+    variants = [{"glv": 0}, {"glv": 1}] if params["kind"] == "weierstrass" else [{}]
+    for n in (n_set, 65536 + 5, 100):            # whole set and prefixes (the small one lives on engine 0 only)
+        for opt in variants:
+            want = single.Parallel.msm(sc1, pts1, n, False, opt)["result"]
+            got = multi.Parallel.msm(scm, ptsm, n, True, opt)
+            assert got["result"] == want, (n, opt)
+    # oracle check on a size it finishes quickly + host-buffer scalars + byte upload through the split
+    n = 70000
+    scalars, points = single.Scalar.toBigints(sc1, 0, n), single.Affine.toBigints(pts1, 0, n)
+    want = _oracle(label, scalars, points)
+    raw = b"".join(s.to_bytes(32, "little") for s in scalars)
+    up = multi.Parallel.pointsFromBigints(points)
+    assert _strip(multi.Parallel.msm(raw, up, n)["result"]) == _strip(want)
+    assert _strip(multi.Parallel.msm(multi.Parallel.scalarsFromBytes(raw), ptsm, n)["result"]) == _strip(want)
+    assert _strip(multi.Parallel.msm(scm, ptsm, n)["result"]) == _strip(want)
+    multi.close(); single.close()
+
+
+def test_debug_environment_cannot_change_a_result(monkeypatch):
+    """MSMZ_DBG used to reach the kernels; no environment variable may alter a release build's result"""
+    import msm_zprize_amd as m
+    for k, v in {"MSMZ_DBG": "7", "MSMZ_FUSED": "1", "MSMZ_TAIL_SKIP": "0", "MSMZ_ATOMIC_SORT": "1"}.items():
+        monkeypatch.setenv(k, v)
+    m.startThreads()
+    curve = m.Weierstrass.create(m.curves.bls12377Params)
+    n = 2000
+    pts, sc = curve.Parallel.randomPointsFast(n, 5), curve.Parallel.randomScalars(n, 6)
+    want = _oracle("bls12-377", curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
+    assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"] == want
+    curve.close()
