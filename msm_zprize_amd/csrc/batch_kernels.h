@@ -1,0 +1,230 @@
+// One tree round of batched-affine bucket additions (rows a6 / a12 of SURVEY.md section 8).  Included by kernels.h.
+//
+// Pair t of round r adds the two operands its descriptor names (plan_kernels.h; the schedule is the reference's,
+// msm-batched-affine.ts:232-247) and writes record base_r + t of the round's compact, chunk-interleaved result
+// array (limb form, kernels.h).  Round 0 gathers the original points.
+//
+// Batch inversion (Montgomery's trick) on two levels:
+//   * each thread walks B pairs like batchAddUnsafeNew (curve-affine.ts:463-522): the forward pass keeps a running
+//     product of the denominators and parks  z_i = numerator_i * prod_{j<i} d_j  in the pair's output record; the
+//     backward pass reads the descriptor again, reloads x1, (x2, y2) and z_i and turns z_i into the slope with the
+//     running inverse;
+//   * the T per-thread products of a workgroup are inverted together: product tree in LDS, ONE field
+//     inversion (wave 0, fe_inverse_wave), down-sweep.
+// 6 field products per addition + (3 T + inversion) per workgroup of T*B additions.
+// Slope/sum formulas use P2 (y3 = m (x2 - x3) - y2, wasm/curve.ts:63-84 addAffinePacked).
+//
+// SAFE handles infinity operands, equal points (doubling, denominator 2y) and opposite points
+// (result infinity) like batchAddNew (curve-affine.ts:376-458); the unsafe variant assumes distinct
+// x like batchAddUnsafeNew and raises meta->error if a zero denominator poisons a batch.
+#pragma once
+
+namespace msmz {
+
+#ifndef MSMZ_BATCH_BMAX
+#define MSMZ_BATCH_BMAX 32
+#endif
+enum { PK_NONE = 0, PK_ADD = 1, PK_DBL = 2, PK_TAKE_A = 3, PK_TAKE_B = 4, PK_INF = 5 };
+
+template <class F, int T, bool SAFE, int OCC, int BMAX>
+__global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint2* desc, int r,
+                                                      int B, MsmMeta* meta) {
+  // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
+  // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
+  __shared__ int32_t tree[F::N * T];
+  __shared__ uint8_t s_kind[SAFE ? BMAX * T : 1];
+  constexpr int N = F::N;
+  const uint32_t out_base = meta->round_base[r];
+  const uint32_t total = meta->round_pairs[r];
+  const uint2* dsc = desc + out_base;
+  const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
+
+  Fe<F> prefix;
+  fe_set_const<F>(prefix, F::ONE);
+  // ---------------------------------------------------------------- forward pass
+#pragma unroll 1
+  for (int i = 0; i < B; i++) {
+    const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
+    uint32_t kind = PK_NONE;
+    if (t < total) {
+      uint2 dd = dsc[t];
+#ifdef MSMZ_EXP_LOCALMEM   // timing experiment (wrong results): every operand from a small cache-resident set
+      dd.x = LOC_ORIG | (t & 4095u);
+      dd.y = LOC_ORIG | ((t + 1u) & 4095u);
+#endif
+      Affine<F> p1, p2;
+      const bool infA = load_operand<F, SAFE>(p1, dd.x, slots, points);
+      const bool infB = load_operand<F, SAFE>(p2, dd.y, slots, points);
+      Fe<F> d, num;
+      fe_sub(d, p2.x, p1.x);
+      fe_sub(num, p2.y, p1.y);
+      kind = PK_ADD;
+      if (SAFE) {
+        if (infA) {
+          kind = infB ? PK_INF : PK_TAKE_B;
+        } else if (infB) {
+          kind = PK_TAKE_A;
+        } else if (fe_is_zero(d)) {
+          if (fe_is_zero(num) && !fe_is_zero(p1.y)) {
+            kind = PK_DBL;
+            fe_add(d, p2.y, p2.y);          // 2y
+            Fe<F> xx;
+            fe_sqr(xx, p2.x);
+            fe_add(num, xx, xx);
+            fe_add(num, num, xx);           // 3x^2
+            fe_carry(num);
+          } else {
+            kind = PK_INF;
+          }
+        }
+      }
+      if (kind == PK_ADD || kind == PK_DBL) {
+        // park z = prefix * numerator in the pair's output record (a product's limbs are valid inputs as they are)
+        Fe<F> z;
+        fe_mul(z, prefix, num);
+#ifdef MSMZ_EXP_LOCALMEM
+        slot_store_fe<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), z);
+#else
+        slot_store_fe<F>(slots + slot_offset<F>(out_base + t), z);
+#endif
+        Fe<F> np;
+        fe_mul(np, prefix, d);
+        prefix = np;
+      }
+    }
+    if (SAFE) s_kind[i * T + threadIdx.x] = (uint8_t)kind;
+  }
+
+  // ---------------------------------------------------------------- workgroup-wide inversion of the T products
+  Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
+  {
+    Fe<F> partner, node;
+#pragma unroll
+    for (int j = 0; j < N; j++) partner.l[j] = __shfl_xor(prefix.l[j], 1, 64);
+    fe_mul(node, prefix, partner);
+    if ((threadIdx.x & 1) == 0) {
+#pragma unroll
+      for (int j = 0; j < N; j++) tree[j * T + (threadIdx.x >> 1)] = node.l[j];
+    }
+  }
+  __syncthreads();
+  int lvl_off = 0;   // offset of the level being consumed (level 1 first)
+#pragma unroll 1
+  for (int width = T >> 2; width >= 1; width >>= 1) {
+    const int child_off = lvl_off;
+    lvl_off += width * 2;
+    if ((int)threadIdx.x < width) {
+      Fe<F> x, y, z;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        x.l[j] = tree[j * T + child_off + 2 * threadIdx.x];
+        y.l[j] = tree[j * T + child_off + 2 * threadIdx.x + 1];
+      }
+      fe_mul(z, x, y);
+#pragma unroll
+      for (int j = 0; j < N; j++) tree[j * T + lvl_off + threadIdx.x] = z.l[j];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 64) {
+    Fe<F> root, inv;
+#pragma unroll
+    for (int j = 0; j < N; j++) root.l[j] = tree[j * T + lvl_off];
+#ifdef MSMZ_EXP_NOINV   // timing experiment (wrong results): no inversion
+    const bool ok = true;
+    inv = root;
+#else
+    const bool ok = fe_inverse_wave(inv, root);
+#endif
+    if (threadIdx.x == 0) {
+      if (!ok) atomicOr(&meta->error, 1u);
+#pragma unroll
+      for (int j = 0; j < N; j++) tree[j * T + lvl_off] = inv.l[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int width = 1; width <= T >> 2; width <<= 1) {
+    const int parent_off = lvl_off;
+    lvl_off -= width * 2;
+    if ((int)threadIdx.x < width) {
+      Fe<F> pi, x, y, xi, yi;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        pi.l[j] = tree[j * T + parent_off + threadIdx.x];
+        x.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x];
+        y.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x + 1];
+      }
+      fe_mul(xi, pi, y);
+      fe_mul(yi, pi, x);
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        tree[j * T + lvl_off + 2 * threadIdx.x] = xi.l[j];
+        tree[j * T + lvl_off + 2 * threadIdx.x + 1] = yi.l[j];
+      }
+    }
+    __syncthreads();
+  }
+  {
+    Fe<F> partner, ninv;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      partner.l[j] = __shfl_xor(prefix.l[j], 1, 64);
+      ninv.l[j] = tree[j * T + (threadIdx.x >> 1)];
+    }
+    fe_mul(run, ninv, partner);
+  }
+
+  // ---------------------------------------------------------------- backward pass
+#pragma unroll 1
+  for (int i = B - 1; i >= 0; i--) {
+    const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
+    if (t >= total) continue;
+    const uint32_t kind = SAFE ? s_kind[i * T + threadIdx.x] : (uint32_t)PK_ADD;
+    uint2 dd = dsc[t];
+#ifdef MSMZ_EXP_LOCALMEM
+    dd.x = LOC_ORIG | (t & 4095u);
+    dd.y = LOC_ORIG | ((t + 1u) & 4095u);
+    uint32_t* out = slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u));
+#else
+    uint32_t* out = slots + slot_offset<F>(out_base + t);
+#endif
+    if (kind == PK_ADD || kind == PK_DBL) {
+      Affine<F> p2;
+      load_operand<F, false>(p2, dd.y, slots, points);
+      Fe<F> z, mm, ms, d, tt, s12;
+      slot_load_fe<F>(z, out);              // parked by the forward pass
+      if (kind == PK_ADD) {
+        Fe<F> x1;
+        load_operand_x<F>(x1, dd.x, slots, points);
+        fe_sub(d, p2.x, x1);
+        fe_add(s12, p2.x, x1);
+      } else {
+        fe_add(d, p2.y, p2.y);
+        fe_add(s12, p2.x, p2.x);
+      }
+      fe_mul(mm, z, run);                 // slope
+      fe_mul(tt, run, d);
+      run = tt;
+      fe_sqr(ms, mm);
+      Affine<F> res;
+      fe_sub(res.x, ms, s12);             // x3 = m^2 - x1 - x2
+      fe_sub(tt, p2.x, res.x);
+      fe_carry(tt);
+      fe_mul(ms, mm, tt);
+      fe_sub(res.y, ms, p2.y);            // y3 = m (x2 - x3) - y2
+      slot_store_point<F>(out, res, false);
+    } else if (kind == PK_TAKE_A || kind == PK_TAKE_B) {
+      Affine<F> p;
+      load_operand<F, false>(p, kind == PK_TAKE_A ? dd.x : dd.y, slots, points);
+      slot_store_point<F>(out, p, false);
+    } else {                              // PK_INF
+      Affine<F> dummy;
+      fe_zero(dummy.x);
+      fe_zero(dummy.y);
+      slot_store_point<F>(out, dummy, true);
+    }
+  }
+}
+
+}  // namespace msmz

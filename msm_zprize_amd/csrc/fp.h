@@ -30,6 +30,16 @@
 #define MSMZ_HD inline
 #endif
 
+// Hide a limb's value range from the optimizer (device code only; no instruction is emitted).  Once LLVM has proved
+// a limb non-negative (a masked product limb, also through a loop phi) it rewrites sext(limb) as zext(limb), and the
+// AMDGPU backend then no longer recognises (int64)a * (int64)b as ONE v_mad_i64_i32: it emits two v_mad_u64_u32 plus
+// two moves per product (seen in k_batch_add's backward pass: 832 + 728 extra instructions per addition).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MSMZ_OPAQUE_LIMB(x) asm("" : "+v"(x))
+#else
+#define MSMZ_OPAQUE_LIMB(x) (void)0
+#endif
+
 namespace msmz {
 
 template <class F>
@@ -111,9 +121,15 @@ MSMZ_HD void fe_normalize(Fe<F>& a) {
 // Column k:  acc += sum_{i+j=k} a_i*b_j  -  sum_{i+j=k, j>=1} m_i*p_j ;  for k < N the new
 // quotient digit m_k = acc*p^-1 mod 2^W makes acc - m_k*p_0 divisible by 2^W.
 template <class F>
-MSMZ_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
+MSMZ_HD void fe_mul(Fe<F>& r, const Fe<F>& a_in, const Fe<F>& b_in) {
   constexpr int N = F::N, W = F::W;
   constexpr uint32_t MASK = (1u << W) - 1;
+  Fe<F> a = a_in, b = b_in;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    MSMZ_OPAQUE_LIMB(a.l[j]);
+    MSMZ_OPAQUE_LIMB(b.l[j]);
+  }
   int32_t m[N];
   int64_t acc = 0;
 #pragma unroll
@@ -143,24 +159,31 @@ MSMZ_HD void fe_mul(Fe<F>& r, const Fe<F>& a, const Fe<F>& b) {
 }
 
 // Montgomery square (multiply-montgomery.ts:138-215): off-diagonal products once, doubled.
+// The doubling is applied to the 64-bit column sum of the off-diagonal products, not to an operand: with a doubled
+// 32-bit operand (a2 = 2 a) the compiler widens it to 64 bits (sext(2a) -> shl(sext a)) and every product becomes
+// two v_mad_u64_u32 plus two moves instead of one v_mad_i64_i32 (seen in the ISA of k_batch_add: +1100 instructions
+// per addition).
 template <class F>
-MSMZ_HD void fe_sqr(Fe<F>& r, const Fe<F>& a) {
+MSMZ_HD void fe_sqr(Fe<F>& r, const Fe<F>& a_in) {
   constexpr int N = F::N, W = F::W;
   constexpr uint32_t MASK = (1u << W) - 1;
-  int32_t m[N], a2[N];
+  Fe<F> a = a_in;
 #pragma unroll
-  for (int j = 0; j < N; j++) a2[j] = a.l[j] * 2;
+  for (int j = 0; j < N; j++) MSMZ_OPAQUE_LIMB(a.l[j]);
+  int32_t m[N];
   int64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 2 * N - 1; k++) {
     const int lo = k - (N - 1) > 0 ? k - (N - 1) : 0;
     const int hi = k < N - 1 ? k : N - 1;
+    int64_t off = 0;
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       const int j = k - i;
-      if (i < j) acc += (int64_t)a2[i] * (int64_t)a.l[j];
-      if (i == j) acc += (int64_t)a.l[i] * (int64_t)a.l[i];
+      if (i < j) off += (int64_t)a.l[i] * (int64_t)a.l[j];
     }
+    acc += off * 2;
+    if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * (int64_t)a.l[k / 2];
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       const int j = k - i;

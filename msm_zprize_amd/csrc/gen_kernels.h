@@ -149,9 +149,15 @@ __device__ __forceinline__ void te_store_niels(uint32_t* rec, const Fe<F>& x, co
 
 // canonical (x | y) -> Niels records
 template <class F>
-__global__ void __launch_bounds__(256) k_te_points_to_niels(uint32_t* out, const uint32_t* in, uint32_t n) {
+__global__ void __launch_bounds__(256) k_te_points_to_niels(uint32_t* out, const uint32_t* in, uint32_t n,
+                                                            uint32_t* err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  {
+    uint32_t w[2 * F::NW];
+    load_words<F>(w, in + (size_t)i * 2 * F::NW);
+    if (words_geq<F::NW>(w, F::PW) || words_geq<F::NW>(w + F::NW, F::PW)) atomicOr(err, 4u);
+  }
   Affine<F> p;
   load_affine<F>(p, in + (size_t)i * 2 * F::NW, 0);
   Fe<F> x, y;

@@ -36,14 +36,14 @@
 #define MSMZ_BATCH_OCC 4
 #endif
 #ifndef MSMZ_BATCH_BMAX
-#define MSMZ_BATCH_BMAX 16
+#define MSMZ_BATCH_BMAX 32
 #endif
 
 #define MSMZ_INST_BATCH(F, Fr, PFX)                                                                               \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, true, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(              \
-      uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, int, MsmMeta*); \
+      uint32_t*, const uint32_t*, const uint2*, int, int, MsmMeta*);                                             \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, false, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(             \
-      uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, int, MsmMeta*);
+      uint32_t*, const uint32_t*, const uint2*, int, int, MsmMeta*);
 
 #define MSMZ_INST_POLICY(P, PFX)                                                                                 \
   PFX template __global__ void k_reduce_quad<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, uint32_t, \
@@ -57,24 +57,28 @@
 
 #define MSMZ_INST_REDUCE(F, Fr, PFX)                                                                              \
   PFX template __global__ void k_reduce_first<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
-                                                 const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,   \
-                                                 uint32_t, const uint32_t*, uint32_t, int, const MsmMeta*);       \
+                                                 const uint4*, uint32_t, uint32_t, uint32_t, uint32_t);           \
   MSMZ_INST_POLICY(WeierPolicy<F>, PFX)
 
 #define MSMZ_INST_REDUCE_TE(F, Fr, PFX) MSMZ_INST_POLICY(TePolicy<F>, PFX)
 
 #define MSMZ_INST_SCALAR(Fr, PFX)                                                                                 \
-  PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int, int); \
+  PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, MsmMeta*, const uint32_t*, uint32_t, int, int, int); \
+  PFX template __global__ void k_hist<Fr, false>(uint32_t*, MsmMeta*, const uint32_t*, SortGeom, uint32_t);       \
+  PFX template __global__ void k_coarse<Fr, false>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, SortGeom, uint32_t); \
+  PFX template __global__ void k_check_scalars<Fr>(uint32_t*, const uint32_t*, uint32_t);                         \
   PFX template __global__ void k_gen_scalars<Fr>(uint32_t*, uint32_t, uint64_t, GenMap);
 
 #define MSMZ_INST_MISC(F, Fr, PFX)                                                                                \
-  PFX template __global__ void k_points_to_mont<F>(uint32_t*, const uint32_t*, const uint8_t*, uint32_t, int);    \
+  PFX template __global__ void k_points_to_mont<F>(uint32_t*, const uint32_t*, const uint8_t*, uint32_t, int, uint32_t*); \
   PFX template __global__ void k_points_from_mont<F>(uint32_t*, const uint32_t*, uint32_t);                       \
-  PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, const uint32_t*, uint32_t, int, int, int, int); \
+  PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, MsmMeta*, const uint32_t*, uint32_t, int, int, int); \
+  PFX template __global__ void k_hist<Fr, true>(uint32_t*, MsmMeta*, const uint32_t*, SortGeom, uint32_t);        \
+  PFX template __global__ void k_coarse<Fr, true>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, SortGeom, uint32_t); \
   MSMZ_INST_SCALAR(Fr, PFX)
 
 #define MSMZ_INST_MISC_TE(F, Fr, PFX)                                                              \
-  PFX template __global__ void k_te_points_to_niels<F>(uint32_t*, const uint32_t*, uint32_t);      \
+  PFX template __global__ void k_te_points_to_niels<F>(uint32_t*, const uint32_t*, uint32_t, uint32_t*); \
   PFX template __global__ void k_te_points_from_niels<F>(uint32_t*, const uint32_t*, uint32_t);    \
   MSMZ_INST_SCALAR(Fr, PFX)
 

@@ -36,8 +36,8 @@ constexpr uint32_t REF_IDX = 0x7fffffffu;
 struct MsmMeta {               // small device-resident block of run-time totals
   uint32_t max_bucket;         // largest bucket size
   uint32_t n_entries;          // E = number of non-zero digits = point additions' inputs
-  uint32_t error;              // bit 0: zero denominator hit in the unsafe batch add
-  uint32_t pad;
+  uint32_t error;              // bit 0: zero denominator hit in the unsafe batch add; bit 1: a scalar did not fit K windows
+  uint32_t rounds;             // tree rounds the plan scheduled
   uint32_t round_pairs[32];    // number of pairs in tree round r
   uint32_t round_base[32];     // first record of round r's result array inside `slots` (prefix sum of round_pairs)
 };
@@ -104,15 +104,88 @@ __device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, 
   store_words<F, NT>(rec, w, cs);
 }
 
-// Slot arrays (results of the tree rounds) are chunk-interleaved in groups of 64 records: chunk q (16 bytes) of
-// record r sits at 16-byte unit (r / 64) * 64 * CH + q * 64 + r % 64, CH = chunks per record.  A wave whose lanes hold
-// consecutive records (the writers) then moves one contiguous KB per load/store instruction, and the readers of the
-// next round (lane i wants records 2i, 2i + 1) two KB, instead of 64 pieces 96 bytes apart.
+// Slot arrays (results of the tree rounds) hold affine points in LIMB form: the N signed limbs of x, then the N limbs
+// of y, one 32-bit word each (28 words for the 377/381-bit fields, 18 -> padded to 20 for the 255-bit ones), values
+// reduced to [0, 3p) with normalized limbs; the all-zero record is the point at infinity.  Nothing is packed or
+// unpacked on the way between two tree rounds (that cost ~480 of ~4300 instructions per addition).
+// The arrays are chunk-interleaved in groups of 64 records: chunk q (16 bytes) of record r sits at 16-byte unit
+// (r / 64) * 64 * CH + q * 64 + r % 64, CH = chunks per record.  A wave whose lanes hold consecutive records (the
+// writers) then moves one contiguous KB per load/store instruction, and the readers of the next round (lane i wants
+// records 2i, 2i + 1) two KB, instead of 64 pieces a record apart.
 constexpr int SLOT_CS = 64;
 template <class F>
+struct SlotFmt {
+  static constexpr int WORDS = (2 * F::N + 3) / 4 * 4;   // words per record
+  static constexpr int CH = WORDS / 4;                   // 16-byte chunks per record
+  static constexpr int XCH = (F::N + 3) / 4;             // chunks that cover x (and, padded, a parked field element)
+};
+template <class F>
 __device__ __forceinline__ size_t slot_offset(uint32_t rec) {   // in 32-bit words
-  constexpr int CH = (2 * F::NW) / 4;
-  return ((size_t)(rec >> 6) * (CH * 64) + (rec & 63u)) * 4;
+  return ((size_t)(rec >> 6) * (SlotFmt<F>::CH * 64) + (rec & 63u)) * 4;
+}
+
+// first NCH chunks of a slot record -> words
+template <int NCH>
+__device__ __forceinline__ void slot_load_chunks(uint32_t* w, const uint32_t* rec) {
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(rec);
+#pragma unroll
+  for (int i = 0; i < NCH; i++) {
+    const u32x4 v = s4[i * SLOT_CS];
+    w[4 * i] = v.x;
+    w[4 * i + 1] = v.y;
+    w[4 * i + 2] = v.z;
+    w[4 * i + 3] = v.w;
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void slot_store_chunks(uint32_t* rec, const uint32_t* w) {
+  u32x4* d4 = reinterpret_cast<u32x4*>(rec);
+#pragma unroll
+  for (int i = 0; i < NCH; i++) {
+    const u32x4 v = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+    d4[i * SLOT_CS] = v;
+  }
+}
+
+// whole record; returns true if it is the point at infinity (only evaluated when CHECK_INF)
+template <class F, bool CHECK_INF>
+__device__ __forceinline__ bool slot_load_point(Affine<F>& p, const uint32_t* rec) {
+  uint32_t w[SlotFmt<F>::WORDS];
+  slot_load_chunks<SlotFmt<F>::CH>(w, rec);
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < F::N; j++) {
+    p.x.l[j] = (int32_t)w[j];
+    p.y.l[j] = (int32_t)w[F::N + j];
+    if (CHECK_INF) o |= w[j] | w[F::N + j];
+  }
+  return CHECK_INF && o == 0;
+}
+template <class F>
+__device__ __forceinline__ void slot_load_fe(Fe<F>& x, const uint32_t* rec) {   // the x limbs / a parked element
+  uint32_t w[SlotFmt<F>::XCH * 4];
+  slot_load_chunks<SlotFmt<F>::XCH>(w, rec);
+#pragma unroll
+  for (int j = 0; j < F::N; j++) x.l[j] = (int32_t)w[j];
+}
+template <class F>
+__device__ __forceinline__ void slot_store_fe(uint32_t* rec, const Fe<F>& x) {
+  uint32_t w[SlotFmt<F>::XCH * 4];
+#pragma unroll
+  for (int j = 0; j < SlotFmt<F>::XCH * 4; j++) w[j] = j < F::N ? (uint32_t)x.l[j] : 0u;
+  slot_store_chunks<SlotFmt<F>::XCH>(rec, w);
+}
+// x, y: any lazy values |v| < 2^4 p; stored reduced to [0, 3p) with normalized limbs
+template <class F>
+__device__ __forceinline__ void slot_store_point(uint32_t* rec, const Affine<F>& p, bool inf) {
+  uint32_t w[SlotFmt<F>::WORDS];
+  Fe<F> x = p.x, y = p.y;
+  fe_reduce_small(x);
+  fe_reduce_small(y);
+#pragma unroll
+  for (int j = 0; j < SlotFmt<F>::WORDS; j++)
+    w[j] = inf ? 0u : (j < F::N ? (uint32_t)x.l[j] : (j < 2 * F::N ? (uint32_t)y.l[j - F::N] : 0u));
+  slot_store_chunks<SlotFmt<F>::CH>(rec, w);
 }
 
 template <class F>
@@ -142,10 +215,16 @@ __device__ __forceinline__ void store_xyzz(uint32_t* rec, const Xyzz<F>& p) {
 // out: n records in memory format; with `endo`, records [n, 2n) hold (beta*x, y)
 template <class F>
 __global__ void __launch_bounds__(256) k_points_to_mont(uint32_t* out, const uint32_t* in, const uint8_t* is_inf,
-                                                        uint32_t n, int endo) {
+                                                        uint32_t n, int endo, uint32_t* err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> p, m;
+  {
+    // coordinates must be canonical (< p); flagged here instead of in a serial host loop
+    uint32_t w[2 * F::NW];
+    load_words<F>(w, in + (size_t)i * 2 * F::NW);
+    if (words_geq<F::NW>(w, F::PW) || words_geq<F::NW>(w + F::NW, F::PW)) atomicOr(err, 4u);
+  }
   bool inf = load_affine<F>(p, in + (size_t)i * 2 * F::NW, 0);
   (void)inf;
   bool flagged = is_inf != nullptr && is_inf[i] != 0;
@@ -182,40 +261,23 @@ __global__ void __launch_bounds__(256) k_points_from_mont(uint32_t* out, const u
   store_words<F>(out + (size_t)i * 2 * F::NW, w);
 }
 
-// ------------------------------------------------------------------------------------------------ digits
-// digits[k*M + i] for i in [0, M): M = N (no GLV) or 2N (GLV: entry N+i is the endomorphism half).
-// `shift` = 0: counts[] is the per-bucket histogram (one global atomic per entry; fallback path).
-// shift = FB > 0 (two-level sort): counts[] is the per-coarse-bin histogram, bin = k * (L >> FB) + ((l-1) >> FB),
-// accumulated in LDS (dynamic shared memory: K * (L >> FB) words) and flushed with one atomic per bin.
-constexpr int DIGITS_ITEMS = 8;
-
-template <class Fr, bool GLV>
+// ------------------------------------------------------------------------------------------------ digits (fallback sort)
+// Used only when the window size leaves more coarse bins than the LDS-staged sort handles (sort_kernels.h): the
+// digits are materialized, digits[k*M + i] for i in [0, M) -- M = N (no GLV) or 2N (GLV: entry N+i is the
+// endomorphism half) -- and counts[] is the per-bucket histogram (one global atomic per entry).
 // `spread` = sb > 0: the top window has few significant bits, so its entries are dealt over 2^sb
 // sub-windows K-1 .. K-1+2^sb-1 by the low bits of the point index (every sub-window keeps the weight
 // 2^(c(K-1))); this keeps bucket sizes balanced (the job of splitBuckets' special case for the sparse top
 // window, msm-common.ts:105-112, 146-174).
-__global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* counts, const uint32_t* scalars,
-                                                uint32_t n, int c, int K, int shift, int spread) {
-  extern __shared__ uint32_t s_hist[];
+constexpr int DIGITS_ITEMS = 8;
+
+template <class Fr, bool GLV>
+__global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* counts, MsmMeta* meta, const uint32_t* scalars,
+                                                uint32_t n, int c, int K, int spread) {
   const uint32_t L = 1u << (c - 1);
   const uint32_t M = GLV ? 2 * n : n;
-  const uint32_t bins_per_window = L >> shift;
-  const uint32_t nbins = (uint32_t)(K - 1 + (1 << spread)) * bins_per_window;
   const uint32_t smask = (1u << spread) - 1u;
-  if (shift) {
-    for (uint32_t b = threadIdx.x; b < nbins; b += 256) s_hist[b] = 0;
-    __syncthreads();
-  }
-  auto tally = [&](uint32_t k, uint32_t l, uint32_t entry) {
-    if (l == 0) return;
-    if (k == (uint32_t)(K - 1)) k += entry & smask;
-    const uint32_t bin = k * bins_per_window + ((l - 1) >> shift);
-    if (shift) {
-      atomicAdd(&s_hist[bin], 1u);
-    } else {
-      atomicAdd(&counts[bin], 1u);
-    }
-  };
+  uint32_t bad = 0;
 #pragma unroll 1
   for (int item = 0; item < DIGITS_ITEMS; item++) {
     const uint32_t i = (blockIdx.x * DIGITS_ITEMS + item) * 256 + threadIdx.x;
@@ -227,48 +289,57 @@ __global__ void __launch_bounds__(256) k_digits(uint32_t* digits, uint32_t* coun
       s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
       s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
     }
+    if (words_geq<8>(s, Fr::Q)) bad |= 4u;
+    constexpr int HALVES = GLV ? 2 : 1;
+    constexpr int HW = GLV ? 4 : 8;
+    uint32_t h[HALVES][HW], neg[HALVES];
     if constexpr (GLV) {
-      uint32_t h[2][4], neg[2];
       glv_decompose<Fr>(h[0], h[1], neg[0], neg[1], s);
-#pragma unroll
-      for (int half = 0; half < 2; half++) {
-        uint32_t carry = 0;
-        for (int k = 0; k < K; k++) {
-          uint32_t l = extract_bits<4>(h[half], k * c, c) + carry;
-          if (l > L) {
-            l = 2 * L - l;
-            carry = 1;
-          } else {
-            carry = 0;
-          }
-          // the half scalar's own sign flips every digit's sign
-          uint32_t ng = (carry ^ neg[half]) & (l != 0 ? 1u : 0u);
-          digits[(size_t)k * M + (size_t)half * n + i] = l | (ng << 31);
-          tally(k, l, half * n + i);
-        }
-      }
     } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) h[0][j] = s[j];
+      neg[0] = 0;
+    }
+#pragma unroll
+    for (int half = 0; half < HALVES; half++) {
       uint32_t carry = 0;
       for (int k = 0; k < K; k++) {
-        uint32_t l = extract_bits<8>(s, k * c, c) + carry;
+        uint32_t l = extract_bits<HW>(h[half], k * c, c) + carry;
         if (l > L) {
           l = 2 * L - l;
           carry = 1;
         } else {
           carry = 0;
         }
-        digits[(size_t)k * M + i] = l | (carry << 31);
-        tally(k, l, i);
+        // the half scalar's own sign flips every digit's sign
+        const uint32_t ng = (carry ^ neg[half]) & (l != 0 ? 1u : 0u);
+        const uint32_t entry = half * n + i;
+        digits[(size_t)k * M + entry] = l | (ng << 31);
+        if (l != 0) {
+          const uint32_t kw = k == K - 1 ? (uint32_t)k + (entry & smask) : (uint32_t)k;
+          atomicAdd(&counts[kw * L + (l - 1)], 1u);
+        }
       }
+      // does the scalar fit K windows?  (a carry out of the last one, or bits beyond it)
+      if (carry) bad |= 2u;
+      for (int pos = K * c; pos < 32 * HW; pos += 16)
+        if (extract_bits<HW>(h[half], pos, 16) != 0) bad |= 2u;
     }
   }
-  if (shift) {
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
-      const uint32_t v = s_hist[b];
-      if (v) atomicAdd(&counts[b], v);
-    }
-  }
+  if (bad) atomicOr(&meta->error, bad);
+}
+
+// upload-time range check of resident scalars (scalarsFromBytes, parallel.ts:114-133: values < group order)
+template <class Fr>
+__global__ void __launch_bounds__(256) k_check_scalars(uint32_t* err, const uint32_t* scalars, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 a = p4[0], b = p4[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  if (words_geq<8>(s, Fr::Q)) atomicOr(err, 4u);
 }
 
 // ------------------------------------------------------------------------------------------------ scans
@@ -399,262 +470,52 @@ static __global__ void __launch_bounds__(256) k_scatter(uint32_t* refs, uint32_t
   }
 }
 
-// ------------------------------------------------------------------------------------------------ two-level sort
-// Replacement for {global-atomic histogram, k_scatter} when M <= 2^24: a most-significant-digit radix
-// partition of the (bucket, reference) pairs in two LDS-staged passes, so that no pass issues one
-// global atomic per entry and every global store instruction writes contiguous runs.
-//
-//   digit l in [1, L]  ->  i = l - 1 = (coarse << FB) | fine,   FB = min(8, c-1) fine bits
-//   coarse bin  id  = k * NCB + coarse      (NCB = 2^(c-1-FB) bins per window; consecutive buckets)
-//
-//   k_digits (SORT2 mode)  per-workgroup LDS histogram of coarse bins, flushed with one atomic per bin
-//   scan                   bin offsets (tiny)
-//   k_scatter_coarse       THE HBM-bound bucket scatter: reads each digit (4 B), stages a tile in LDS sorted
-//                          by coarse bin, writes (fine | negate | index) words (4 B) in contiguous runs
-//   k_sort_fine            one workgroup per coarse bin: LDS histogram of its <= 256 buckets -> bucket
-//                          offsets `off`, then places every reference at its final sorted position
-constexpr int SORT_FB_MAX = 8;     // (historic default) fine bits = min(c-1, 31 - idx_bits, FINE_MAX_BITS)
-constexpr int COARSE_T = 256;
-#ifndef MSMZ_COARSE_ITEMS
-#define MSMZ_COARSE_ITEMS 32
-#endif
-constexpr int COARSE_ITEMS = MSMZ_COARSE_ITEMS;
-constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // 8192 entries per workgroup
-constexpr int COARSE_MAX_BINS = 512;                  // bins per window the LDS staging supports
+}  // namespace msmz
 
-template <int NBINS_MAX>
-static __global__ void __launch_bounds__(COARSE_T) k_scatter_coarse(uint32_t* packed_out, uint32_t* bin_cursor,
-                                                                    const uint32_t* bin_base, const uint32_t* digits,
-                                                                    uint32_t M, int fb, uint32_t ncb_window, int idx_bits,
-                                                                    uint32_t tiles, int spread) {
-  __shared__ uint32_t s_cnt[NBINS_MAX + 1];   // entries of this tile per bin, then exclusive scan (+ total)
-  __shared__ uint32_t s_gbase[NBINS_MAX];     // global address of this tile's run in each bin
-  __shared__ uint32_t s_stage[COARSE_TILE];
-  __shared__ uint32_t s_wave[COARSE_T / 64];
-  constexpr int VEC = COARSE_ITEMS / 4;       // uint4 loads per thread
-  const uint32_t k = blockIdx.y;
-  const uint32_t* dk = digits + (size_t)k * M;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the top window's tile is dealt over 2^spread sub-windows: (index & mask) selects the sub-window,
-  // whose bins follow each other in the global bin order
-  const bool top = (k + 1 == gridDim.y) && spread > 0;
-  const uint32_t smask = top ? (1u << spread) - 1u : 0u;
-  const uint32_t ncb = top ? ncb_window << spread : ncb_window;
+#include "sort_kernels.h"
+#include "plan_kernels.h"
 
-  auto load_tile = [&](uint32_t tile, uint4* v) {
-    const uint32_t tile0 = tile * COARSE_TILE;
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      const uint32_t i = tile0 + (j * COARSE_T + threadIdx.x) * 4;
-      if (i + 3 < M) {
-        v[j] = *reinterpret_cast<const uint4*>(dk + i);
-      } else {
-        v[j].x = i < M ? dk[i] : 0u;
-        v[j].y = i + 1 < M ? dk[i + 1] : 0u;
-        v[j].z = i + 2 < M ? dk[i + 2] : 0u;
-        v[j].w = 0u;
-      }
-    }
-  };
+namespace msmz {
 
-  uint4 cur[VEC], nxt[VEC];
-  uint32_t tile = blockIdx.x;
-  if (tile < tiles) load_tile(tile, cur);
-  for (; tile < tiles; tile += gridDim.x) {
-    const uint32_t tile0 = tile * COARSE_TILE;
-    const bool more = tile + gridDim.x < tiles;
-    if (more) load_tile(tile + gridDim.x, nxt);   // prefetch the next tile under this tile's LDS phases
-    for (uint32_t b = threadIdx.x; b <= ncb; b += COARSE_T) s_cnt[b] = 0;
-    __syncthreads();
-    uint32_t val[COARSE_ITEMS], rank[COARSE_ITEMS];
-    uint16_t bin[COARSE_ITEMS];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      const uint32_t d4[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int e = j * 4 + q;
-        const uint32_t i = tile0 + (j * COARSE_T + threadIdx.x) * 4 + q;
-        const uint32_t d = d4[q];
-        const uint32_t l = d & REF_IDX;
-        bin[e] = 0xffff;
-        if (l != 0) {
-          const uint32_t idx = l - 1;
-          bin[e] = (uint16_t)((i & smask) * ncb_window + (idx >> fb));
-          val[e] = ((idx & ((1u << fb) - 1u)) << (idx_bits + 1)) | ((d >> 31) << idx_bits) | i;
-          rank[e] = atomicAdd(&s_cnt[bin[e]], 1u);
-        }
-      }
-    }
-    __syncthreads();
-    // reserve the runs in global memory, and scan the counts for the staging order
-    uint32_t my_cnt[NBINS_MAX / COARSE_T], my_sum = 0;
-#pragma unroll
-    for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
-      const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
-      my_cnt[q] = b < ncb ? s_cnt[b] : 0;
-      my_sum += my_cnt[q];
-    }
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan(my_sum, &total, s_wave);
-#pragma unroll
-    for (int q = 0; q < NBINS_MAX / COARSE_T; q++) {
-      const uint32_t b = threadIdx.x * (NBINS_MAX / COARSE_T) + q;
-      if (b < ncb) {
-        s_cnt[b] = ex;
-        const uint32_t gb = k * ncb_window + b;
-        s_gbase[b] = my_cnt[q] ? bin_base[gb] + atomicAdd(&bin_cursor[gb], my_cnt[q]) : 0u;
-        ex += my_cnt[q];
-      }
-    }
-    if (threadIdx.x == 0) s_cnt[ncb] = total;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < COARSE_ITEMS; e++)
-      if (bin[e] != 0xffff) s_stage[s_cnt[bin[e]] + rank[e]] = val[e];
-    __syncthreads();
-    // one wave per bin: each run is a contiguous, coalesced store
-    for (uint32_t b = wave; b < ncb; b += COARSE_T / 64) {
-      const uint32_t r0 = s_cnt[b], r1 = s_cnt[b + 1], g = s_gbase[b];
-      for (uint32_t p = r0 + lane; p < r1; p += 64) packed_out[g + (p - r0)] = s_stage[p];
-    }
-    __syncthreads();
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
-    }
-  }
-}
-
-// One workgroup per coarse bin.  Phase A: histogram of the bin's buckets in LDS -> off[] for those buckets
-// (+ running maximum bucket size).  Phase B: every reference goes to its final sorted position; when the
-// whole bin fits the LDS staging buffer (the normal case) the positions are filled in LDS and the bin is
-// written out as one contiguous, coalesced stream -- scattered 4-byte stores cost ~8x write amplification
-// (profiles/r01_pmc_write_summary.txt) -- otherwise straight to memory.
-constexpr int FINE_MAX_BITS = 11;
-constexpr int FINE_T = 1024;
-constexpr int FINE_STAGE = 38400;   // entries staged in LDS: 150 KB + 8 KB of counters < 160 KB
-
-static __global__ void __launch_bounds__(FINE_T) k_sort_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
-                                                             const uint32_t* packed, const uint32_t* bin_base, int fb,
-                                                             uint32_t n_bins, int idx_bits, uint32_t n_half,
-                                                             uint32_t endo_delta) {
-  extern __shared__ uint32_t s_dyn[];
-  uint32_t* s_cnt = s_dyn;                                  // [1 << FINE_MAX_BITS] counts, then running cursors
-  uint32_t* s_stage = s_dyn + (1 << FINE_MAX_BITS);          // [FINE_STAGE]
-  __shared__ uint32_t s_wave[FINE_T / 64];
-  const uint32_t bin = blockIdx.x;
-  const uint32_t nfine = 1u << fb;
-  const uint32_t per = (nfine + FINE_T - 1) / FINE_T;        // consecutive buckets per thread
-  const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
-  const bool staged = (end - begin) <= (uint32_t)FINE_STAGE;
-  for (uint32_t f = threadIdx.x; f < nfine; f += FINE_T) s_cnt[f] = 0;
-  __syncthreads();
-  for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
-  __syncthreads();
-  uint32_t mine = 0, mx = 0, cnts[2] = {0, 0};
-  for (uint32_t j = 0; j < per; j++) {
-    const uint32_t f = threadIdx.x * per + j;
-    const uint32_t c = f < nfine ? s_cnt[f] : 0;
-    cnts[j & 1] = c;
-    mine += c;
-    mx = c > mx ? c : mx;
-  }
-  // block-wide exclusive scan of `mine` over FINE_T threads
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t x = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
-  if (lane == 63) s_wave[wave] = x;
-  __syncthreads();
-  uint32_t wbase = 0;
-  for (int w2 = 0; w2 < wave; w2++) wbase += s_wave[w2];
-  uint32_t ex = wbase + x - mine;                            // relative to the bin start
-  for (uint32_t j = 0; j < per; j++) {
-    const uint32_t f = threadIdx.x * per + j;
-    if (f < nfine) {
-      s_cnt[f] = ex;                                         // becomes the running cursor of bucket f
-      off[(size_t)bin * nfine + f] = begin + ex;
-      ex += cnts[j & 1];
-    }
-  }
-  if (mx > 1) atomicMax(max_bucket, mx);
-  if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
-  __syncthreads();
-  const uint32_t imask = (1u << idx_bits) - 1u;
-  for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) {
-    const uint32_t v = packed[p];
-    const uint32_t pos = atomicAdd(&s_cnt[v >> (idx_bits + 1)], 1u);
-    uint32_t idx = v & imask;
-    if (idx >= n_half) idx += endo_delta;   // endomorphism half: record index in the point set
-    const uint32_t ref = idx | (((v >> idx_bits) & 1u) << 31);
-    if (staged) s_stage[pos] = ref; else refs[begin + pos] = ref;
-  }
-  if (staged) {
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < end - begin; p += FINE_T) refs[begin + p] = s_stage[p];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ batch add
-// Round r (m = 2^r) of the in-bucket pair tree: inside each bucket (positions relative to its start)
-// element j*2m + m is added into element j*2m, for every j with j*2m + m < size -- exactly the
-// reference's schedule (msm-batched-affine.ts:232-247).
-//
-// Storage: the reference adds in place in its sorted point array.  Here every round writes a COMPACT
-// result array R_r inside `slots` (record base[r] + t for pair t of the round; pairs are numbered bucket by
-// bucket through rscan_r), so a workgroup's stores are one contiguous stream and round r+1 reads its two
-// operands from adjacent records of R_r.  The value of relative position `pos` of bucket g before round
-// r is therefore found at
-//     R_rr[rscan_rr[g] + pos / 2^(rr+1)],   rr = min(r-1, floor(log2(size-pos-1)))     (size-pos >= 2)
-//     the original point refs[start+pos]                                               (size-pos == 1 or r == 0)
-// (rr = the last round in which `pos` had a partner).  Round 0 gathers the original points through `refs`.
-//
-// Batch inversion (Montgomery's trick) on two levels:
-//   * each thread walks B pairs like batchAddUnsafeNew (curve-affine.ts:463-522): forward pass keeps a
-//     running product of the denominators and parks  [x1 | z_i = numerator_i * prod_{j<i} d_j]  in the pair's
-//     output record; backward pass turns z_i into the slope with the running inverse;
-//   * the T per-thread products of a workgroup are inverted together: product tree in LDS, ONE field
-//     inversion (wave 0, every lane on the same value -> no divergence), down-sweep.
-// 6 field products per addition + (3 T + inversion) per workgroup of T*B additions.
-// Slope/sum formulas use P2 (y3 = m (x2 - x3) - y2, wasm/curve.ts:63-84 addAffinePacked).
-//
-// SAFE handles infinity operands, equal points (doubling, denominator 2y) and opposite points
-// (result infinity) like batchAddNew (curve-affine.ts:376-458); the unsafe variant assumes distinct
-// x like batchAddUnsafeNew and raises meta->error if a zero denominator poisons a batch.
-constexpr int BATCH_BMAX = 16;
-enum { PK_NONE = 0, PK_ADD = 1, PK_DBL = 2, PK_TAKE_A = 3, PK_TAKE_B = 4, PK_INF = 5 };
-constexpr uint32_t LOC_ORIG = 0x40000000u;   // location word: bit 30 = original point (bit 31 = negate), else slot record
-
-// location word of the element at relative position `pos` of bucket g (see above)
-__device__ __forceinline__ uint32_t element_location(uint32_t g, uint32_t start, uint32_t size, uint32_t pos, int r,
-                                                     const uint32_t* refs, const uint32_t* rscan_all, uint32_t nb,
-                                                     const MsmMeta* meta) {
-  const uint32_t rem = size - pos;
-  if (r == 0 || rem == 1) {
-    const uint32_t rf = refs[start + pos];
-    return (rf & REF_IDX) | (rf & REF_NEG) | LOC_ORIG;
-  }
-  int rr = 31 - __builtin_clz(rem - 1);
-  if (rr > r - 1) rr = r - 1;
-  return meta->round_base[rr] + rscan_all[(size_t)rr * ((size_t)nb + 1) + g] + (pos >> (rr + 1));
-}
-
-template <class F>
-__device__ __forceinline__ const uint32_t* location_record(uint32_t loc, const uint32_t* slots, const uint32_t* points,
-                                                           uint32_t& neg, int& cs) {
-  constexpr int RW = 2 * F::NW;
+// ------------------------------------------------------------------------------------------------ operands
+// A location word (plan_kernels.h) names an operand of a tree round / a partial bucket sum: an original point
+// (bit 30; bit 31 = negate; packed record in the resident point set) or a slot record (limb form).
+template <class F, bool CHECK_INF>
+__device__ __forceinline__ bool load_operand(Affine<F>& p, uint32_t loc, const uint32_t* slots, const uint32_t* points) {
   if (loc & LOC_ORIG) {
-    neg = loc >> 31;
-    cs = 1;
-    return points + (size_t)(loc & 0x3fffffffu) * RW;
+    uint32_t w[2 * F::NW];
+    load_words<F>(w, points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
+    uint32_t o = 0;
+    if (CHECK_INF) {
+#pragma unroll
+      for (int i = 0; i < 2 * F::NW; i++) o |= w[i];
+    }
+    fe_unpack<F>(p.x, w);
+    Fe<F> y;
+    fe_unpack<F>(y, w + F::NW);
+    fe_cneg(p.y, y, loc >> 31);
+    return CHECK_INF && o == 0;
   }
-  neg = 0;
-  cs = SLOT_CS;
-  return slots + slot_offset<F>(loc);
+  return slot_load_point<F, CHECK_INF>(p, slots + slot_offset<F>(loc));
+}
+// x coordinate only
+template <class F>
+__device__ __forceinline__ void load_operand_x(Fe<F>& x, uint32_t loc, const uint32_t* slots, const uint32_t* points) {
+  if (loc & LOC_ORIG) {
+    uint32_t w[F::NW];
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
+#pragma unroll
+    for (int i = 0; i < F::NW / 4; i++) {
+      const u32x4 v = s4[i];
+      w[4 * i] = v.x;
+      w[4 * i + 1] = v.y;
+      w[4 * i + 2] = v.z;
+      w[4 * i + 3] = v.w;
+    }
+    fe_unpack<F>(x, w);
+  } else {
+    slot_load_fe<F>(x, slots + slot_offset<F>(loc));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ wave-wide inversion
@@ -797,251 +658,11 @@ __device__ __forceinline__ bool fe_inverse_wave(Fe<F>& r, const Fe<F>& x) {
   return true;
 }
 
-// One batch: pairs [block_base, min(block_base + T*B, total)) of round r, B per thread; buckets of these pairs lie
-// in [g_min, g_max] (search window).  LDS: tree[N*T], s_loc[BMAX*T], s_kind[BMAX*T] owned by the caller.
-template <class F, int T, bool SAFE, int BMAX>
-__device__ __forceinline__ void batch_add_chunk(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
-                                                const uint32_t* off, const uint32_t* rscan_all, uint32_t nb, int r, int B,
-                                                MsmMeta* meta, uint32_t block_base, uint32_t total, uint32_t g_min,
-                                                uint32_t g_max, int32_t* tree, uint32_t* s_loc, uint8_t* s_kind) {
-  __shared__ uint32_t s_span[2];
-  constexpr int N = F::N;
-  constexpr int NW = F::NW;
-  constexpr int RW = 2 * NW;
-  const uint32_t out_base = meta->round_base[r];
-  const uint32_t m = 1u << r;
-  const uint32_t* rscan = rscan_all + (size_t)r * ((size_t)nb + 1);
+}  // namespace msmz
 
-  Fe<F> prefix;
-  fe_set_const<F>(prefix, F::ONE);
-  // Buckets spanned by this batch: two lanes search the whole window [g_min, g_max] for the first and the last
-  // pair, every pair then searches only that span (and only upwards of the thread's previous pair).
-  if (threadIdx.x < 2) {
-    uint32_t tt = block_base;
-    if (threadIdx.x == 1) {
-      tt = block_base + (uint32_t)(T * B) - 1;
-      if (tt >= total) tt = total - 1;
-    }
-    uint32_t lo = g_min, hi = g_max + 1;
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (rscan[mid] <= tt) lo = mid; else hi = mid;
-    }
-    s_span[threadIdx.x] = lo;
-  }
-  __syncthreads();
-  uint32_t g_prev = s_span[0];
-  const uint32_t g_last = s_span[1];
-  // ---------------------------------------------------------------- forward pass
-#pragma unroll 1
-  for (int i = 0; i < B; i++) {
-    const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
-    uint32_t kind = PK_NONE, loc_keep = 0;
-    if (t < total) {
-      uint32_t lo = g_prev, hi = g_last + 1;   // invariant rscan[lo] <= t < rscan[hi]
-      while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (rscan[mid] <= t) lo = mid; else hi = mid;
-      }
-      const uint32_t g = lo;
-      g_prev = g;
-      const uint32_t start = off[g], size = off[g + 1] - start;
-      const uint32_t a = (t - rscan[g]) * 2 * m, b = a + m;
-      const uint32_t locA = element_location(g, start, size, a, r, refs, rscan_all, nb, meta);
-      const uint32_t locB = element_location(g, start, size, b, r, refs, rscan_all, nb, meta);
-      uint32_t negA, negB;
-      int csA, csB;
-      const uint32_t* recA = location_record<F>(locA, slots, points, negA, csA);
-      const uint32_t* recB = location_record<F>(locB, slots, points, negB, csB);
-      Affine<F> p1, p2;
-      bool infA = load_affine<F>(p1, recA, negA, csA);
-      bool infB = load_affine<F>(p2, recB, negB, csB);
-      Fe<F> d, num;
-      fe_sub(d, p2.x, p1.x);
-      fe_sub(num, p2.y, p1.y);
-      kind = PK_ADD;
-      loc_keep = locB;
-      if (SAFE) {
-        if (infA) {
-          kind = infB ? PK_INF : PK_TAKE_B;
-        } else if (infB) {
-          kind = PK_TAKE_A;
-          loc_keep = locA;
-        } else if (fe_is_zero(d)) {
-          if (fe_is_zero(num) && !fe_is_zero(p1.y)) {
-            kind = PK_DBL;
-            fe_add(d, p2.y, p2.y);          // 2y
-            Fe<F> xx;
-            fe_sqr(xx, p2.x);
-            fe_add(num, xx, xx);
-            fe_add(num, num, xx);           // 3x^2
-            fe_carry(num);
-          } else {
-            kind = PK_INF;
-          }
-        }
-      }
-      if (kind == PK_ADD || kind == PK_DBL) {
-        // park [x1 | z] in the pair's output record: x1 as the words it came with, z = prefix * numerator
-        Fe<F> z;
-        fe_mul(z, prefix, num);
-        uint32_t w[NW];
-        fe_store_mulout<F>(w, z);
-        uint32_t* out = slots + slot_offset<F>(out_base + t);
-        const u32x4* a4 = reinterpret_cast<const u32x4*>(recA);
-        u32x4* o4 = reinterpret_cast<u32x4*>(out);
-#pragma unroll
-        for (int q = 0; q < NW / 4; q++) o4[q * SLOT_CS] = a4[q * csA];
-#pragma unroll
-        for (int q = 0; q < NW / 4; q++) {
-          u32x4 v = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
-          o4[(NW / 4 + q) * SLOT_CS] = v;
-        }
-        Fe<F> np;
-        fe_mul(np, prefix, d);
-        prefix = np;
-      }
-    }
-    s_loc[i * T + threadIdx.x] = loc_keep;
-    s_kind[i * T + threadIdx.x] = (uint8_t)kind;
-  }
+#include "batch_kernels.h"
 
-  // ---------------------------------------------------------------- workgroup-wide inversion of the T products
-  Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
-  {
-    Fe<F> partner, node;
-#pragma unroll
-    for (int j = 0; j < N; j++) partner.l[j] = __shfl_xor(prefix.l[j], 1, 64);
-    fe_mul(node, prefix, partner);
-    if ((threadIdx.x & 1) == 0) {
-#pragma unroll
-      for (int j = 0; j < N; j++) tree[j * T + (threadIdx.x >> 1)] = node.l[j];
-    }
-  }
-  __syncthreads();
-  int lvl_off = 0;   // offset of the level being consumed (level 1 first)
-#pragma unroll 1
-  for (int width = T >> 2; width >= 1; width >>= 1) {
-    const int child_off = lvl_off;
-    lvl_off += width * 2;
-    if ((int)threadIdx.x < width) {
-      Fe<F> x, y, z;
-#pragma unroll
-      for (int j = 0; j < N; j++) {
-        x.l[j] = tree[j * T + child_off + 2 * threadIdx.x];
-        y.l[j] = tree[j * T + child_off + 2 * threadIdx.x + 1];
-      }
-      fe_mul(z, x, y);
-#pragma unroll
-      for (int j = 0; j < N; j++) tree[j * T + lvl_off + threadIdx.x] = z.l[j];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < 64) {
-    Fe<F> root, inv;
-#pragma unroll
-    for (int j = 0; j < N; j++) root.l[j] = tree[j * T + lvl_off];
-    const bool ok = fe_inverse_wave(inv, root);
-    if (threadIdx.x == 0) {
-      if (!ok) atomicOr(&meta->error, 1u);
-#pragma unroll
-      for (int j = 0; j < N; j++) tree[j * T + lvl_off] = inv.l[j];
-    }
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int width = 1; width <= T >> 2; width <<= 1) {
-    const int parent_off = lvl_off;
-    lvl_off -= width * 2;
-    if ((int)threadIdx.x < width) {
-      Fe<F> pi, x, y, xi, yi;
-#pragma unroll
-      for (int j = 0; j < N; j++) {
-        pi.l[j] = tree[j * T + parent_off + threadIdx.x];
-        x.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x];
-        y.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x + 1];
-      }
-      fe_mul(xi, pi, y);
-      fe_mul(yi, pi, x);
-#pragma unroll
-      for (int j = 0; j < N; j++) {
-        tree[j * T + lvl_off + 2 * threadIdx.x] = xi.l[j];
-        tree[j * T + lvl_off + 2 * threadIdx.x + 1] = yi.l[j];
-      }
-    }
-    __syncthreads();
-  }
-  {
-    Fe<F> partner, ninv;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-      partner.l[j] = __shfl_xor(prefix.l[j], 1, 64);
-      ninv.l[j] = tree[j * T + (threadIdx.x >> 1)];
-    }
-    fe_mul(run, ninv, partner);
-  }
-
-  // ---------------------------------------------------------------- backward pass
-#pragma unroll 1
-  for (int i = B - 1; i >= 0; i--) {
-    const uint32_t kind = s_kind[i * T + threadIdx.x];
-    if (kind == PK_NONE) continue;
-    const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
-    uint32_t* out = slots + slot_offset<F>(out_base + t);
-    uint32_t neg;
-    int cs;
-    const uint32_t* rec = location_record<F>(s_loc[i * T + threadIdx.x], slots, points, neg, cs);
-    if (kind == PK_ADD || kind == PK_DBL) {
-      Affine<F> p2;
-      load_affine<F>(p2, rec, neg, cs);
-      Fe<F> x1, z, mm, ms, d, tt;
-      {
-        uint32_t w[RW];
-        load_words<F>(w, out, SLOT_CS);   // [x1 | z] parked by the forward pass
-        fe_unpack<F>(x1, w);
-        fe_unpack<F>(z, w + NW);
-      }
-      if (kind == PK_ADD) {
-        fe_sub(d, p2.x, x1);
-      } else {
-        fe_add(d, p2.y, p2.y);
-      }
-      fe_mul(mm, z, run);                 // slope
-      fe_mul(tt, run, d);
-      run = tt;
-      fe_sqr(ms, mm);
-      Affine<F> res;
-      fe_sub(tt, ms, x1);
-      fe_sub(res.x, tt, p2.x);            // x3 = m^2 - x1 - x2
-      fe_sub(tt, p2.x, res.x);
-      fe_carry(tt);
-      fe_mul(ms, mm, tt);
-      fe_sub(res.y, ms, p2.y);            // y3 = m (x2 - x3) - y2
-      store_affine<F>(out, res, false, SLOT_CS);
-    } else if (kind == PK_TAKE_A || kind == PK_TAKE_B) {
-      Affine<F> p;
-      load_affine<F>(p, rec, neg, cs);
-      store_affine<F>(out, p, false, SLOT_CS);
-    } else {                              // PK_INF
-      Affine<F> dummy;
-      store_affine<F>(out, dummy, true, SLOT_CS);
-    }
-  }
-}
-
-// One launch per tree round (any bucket sizes): workgroup w handles pairs [w*T*B, (w+1)*T*B) of round r.
-template <class F, int T, bool SAFE, int OCC, int BMAX>
-__global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint32_t* refs,
-                                                      const uint32_t* off, const uint32_t* rscan_all, uint32_t nb, int r,
-                                                      int B, MsmMeta* meta) {
-  // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
-  // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
-  __shared__ int32_t tree[F::N * T];
-  __shared__ uint32_t s_loc[BMAX * T];    // location word of operand B (of operand A for PK_TAKE_A)
-  __shared__ uint8_t s_kind[BMAX * T];
-  batch_add_chunk<F, T, SAFE, BMAX>(slots, points, refs, off, rscan_all, nb, r, B, meta,
-                                    blockIdx.x * (uint32_t)(T * B), meta->round_pairs[r], 0u, nb - 1, tree, s_loc, s_kind);
-}
+namespace msmz {
 
 // ------------------------------------------------------------------------------------------------ 4-lane point addition
 // The upper reduction levels are latency-bound (a handful of waves, each alone on its SIMD, running 14
@@ -1253,24 +874,20 @@ __global__ void __launch_bounds__(128) k_bucket_accumulate(uint32_t* partial, co
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
-// run += (sum of bucket g).  After `rounds_done` tree rounds a bucket of `size` elements is left as
-// ceil(size / 2^rounds_done) partial sums (one for all but the longest buckets: the host stops the tree rounds two
-// short of log2(longest bucket), because a round costs ~80 us of latency however few pairs it has); partial sum i
-// covers the elements from position i * 2^rounds_done and lives where element_location says.
+// run += (sum of bucket g): the <= 4 partial sums the tree rounds left of it, at the locations the plan recorded
+// (one for all but the longest buckets: the rounds stop two short of log2(longest bucket), because a round costs
+// ~80 us of latency however few pairs it has).
 template <class F>
 __device__ __forceinline__ void add_bucket(Xyzz<F>& run, uint32_t g, const uint32_t* slots, const uint32_t* points,
-                                           const uint32_t* refs, const uint32_t* off, const uint32_t* rscan_all,
-                                           uint32_t nb, int rounds_done, const MsmMeta* meta) {
-  const uint32_t start = off[g], size = off[g + 1] - start;
-  const uint32_t step = 1u << rounds_done;
+                                           const uint4* bfin) {
+  const uint4 fin = bfin[g];
+  const uint32_t locs[4] = {fin.x, fin.y, fin.z, fin.w};
 #pragma unroll 1
-  for (uint32_t pos = 0; pos < size; pos += step) {
-    const uint32_t loc = element_location(g, start, size, pos, rounds_done, refs, rscan_all, nb, meta);
-    uint32_t neg;
-    int cs;
-    const uint32_t* rec = location_record<F>(loc, slots, points, neg, cs);
+  for (int i = 0; i < 4; i++) {
+    const uint32_t loc = locs[i];
+    if (loc == LOC_NONE) break;
     Affine<F> p;
-    const bool inf = load_affine<F>(p, rec, neg, cs);
+    const bool inf = load_operand<F, true>(p, loc, slots, points);
     Xyzz<F> tmp;
     xyzz_madd(tmp, run, p, inf);
     run = tmp;
@@ -1287,10 +904,8 @@ __device__ __forceinline__ void add_bucket(Xyzz<F>& run, uint32_t g, const uint3
 // window) C is W_k.  No per-level power-of-two scaling of the partial sums is needed.
 template <class F>
 __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce_first(uint32_t* rows, uint32_t* tris, const uint32_t* slots,
-                                                      const uint32_t* points, const uint32_t* refs, const uint32_t* off,
-                                                      uint32_t L, uint32_t S, uint32_t groups, uint32_t total,
-                                                      const uint32_t* rscan_all, uint32_t nb, int rounds_done,
-                                                      const MsmMeta* meta) {
+                                                      const uint32_t* points, const uint4* bfin, uint32_t L, uint32_t S,
+                                                      uint32_t groups, uint32_t total) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t k = t / groups, a = t - k * groups;
@@ -1299,11 +914,11 @@ __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce_first(uint32_t*
   xyzz_set_inf(tri);
   for (uint32_t b = S; b-- > 0;) {
     const uint32_t j = a * S + b;           // weight; bucket l = j, j in [0, L)
-    if (j >= 1 && j < L) add_bucket<F>(run, k * L + (j - 1), slots, points, refs, off, rscan_all, nb, rounds_done, meta);
+    if (j >= 1 && j < L) add_bucket<F>(run, k * L + (j - 1), slots, points, bfin);
     if (j == L / 2 && L >= 2) {
       // the single bucket of weight L is folded in as 2 * (L/2): keeps the element count a power of two
       for (int twice = 0; twice < 2; twice++)
-        add_bucket<F>(run, k * L + (L - 1), slots, points, refs, off, rscan_all, nb, rounds_done, meta);
+        add_bucket<F>(run, k * L + (L - 1), slots, points, bfin);
     }
     if (b >= 1) {
       xyzz_add(tmp, tri, run);

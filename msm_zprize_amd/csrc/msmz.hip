@@ -19,10 +19,10 @@ struct WeierCfg {
   using Fr = Fr_;
   static constexpr bool TE = false;
   static constexpr bool HAS_ENDO = true;
-  static int run_msm(Engine<WeierCfg>& e, const Handle& p, const uint32_t* s, uint64_t n, const msmz_opts& o,
-                     uint8_t* out, int* oi, msmz_log* log) {
-    if (o.buckets == MSMZ_BUCKETS_PROJECTIVE) return e.msm_weierstrass_projective(p, s, n, o, out, oi, log);
-    return e.msm_weierstrass_affine(p, s, n, o, out, oi, log);
+  static int run_msm(Engine<WeierCfg>& e, const Handle& p, const uint32_t* pts, const uint32_t* s, uint64_t n,
+                     const msmz_opts& o, uint8_t* out, int* oi, msmz_log* log, int extra_bits) {
+    if (o.buckets == MSMZ_BUCKETS_PROJECTIVE) return e.msm_weierstrass_projective(p, pts, s, n, o, out, oi, log);
+    return e.msm_weierstrass_affine(p, pts, s, n, o, out, oi, log, extra_bits);
   }
 };
 
@@ -32,9 +32,9 @@ struct TeCfg {
   using Fr = Fr_;
   static constexpr bool TE = true;
   static constexpr bool HAS_ENDO = false;
-  static int run_msm(Engine<TeCfg>& e, const Handle& p, const uint32_t* s, uint64_t n, const msmz_opts& o,
-                     uint8_t* out, int* oi, msmz_log* log) {
-    return e.msm_twisted_edwards(p, s, n, o, out, oi, log);
+  static int run_msm(Engine<TeCfg>& e, const Handle& p, const uint32_t* pts, const uint32_t* s, uint64_t n,
+                     const msmz_opts& o, uint8_t* out, int* oi, msmz_log* log, int) {
+    return e.msm_twisted_edwards(p, pts, s, n, o, out, oi, log);
   }
 };
 
@@ -52,60 +52,6 @@ struct msmz_ctx {
   IEngine* engine;
   int n_devices;
 };
-
-template <class F>
-static int point_add_w(const uint8_t* a, int ai, const uint8_t* b, int bi, uint8_t* out, int* oi) {
-  constexpr int NW = F::NW;
-  auto load = [](Xyzz<F>& p, const uint8_t* xy, int inf) {
-    if (inf) {
-      xyzz_set_inf(p);
-      return;
-    }
-    uint32_t w[2 * NW];
-    memcpy(w, xy, sizeof(w));
-    Affine<F> t, m;
-    fe_unpack<F>(t.x, w);
-    fe_unpack<F>(t.y, w + NW);
-    fe_to_mont(m.x, t.x);
-    fe_to_mont(m.y, t.y);
-    xyzz_from_affine(p, m);
-  };
-  Xyzz<F> p, q, r;
-  load(p, a, ai);
-  load(q, b, bi);
-  xyzz_add(r, p, q);
-  uint32_t w[2 * NW];
-  bool inf = xyzz_to_affine_canon<F>(w, r);
-  memcpy(out, w, sizeof(w));
-  *oi = inf ? 1 : 0;
-  return MSMZ_OK;
-}
-
-template <class F>
-static int point_add_te(const uint8_t* a, const uint8_t* b, uint8_t* out, int* oi) {
-  constexpr int NW = F::NW;
-  auto load = [](TeExt<F>& p, const uint8_t* xy) {
-    uint32_t w[2 * NW];
-    memcpy(w, xy, sizeof(w));
-    Fe<F> x, y;
-    fe_unpack<F>(x, w);
-    fe_unpack<F>(y, w + NW);
-    fe_to_mont(p.X, x);
-    fe_to_mont(p.Y, y);
-    fe_set_const<F>(p.Z, F::ONE);
-    fe_mul(p.T, p.X, p.Y);
-  };
-  if (!a || !b) return MSMZ_ERR_ARG;   // twisted Edwards has no infinity flag: the identity is (0, 1)
-  TeExt<F> p, q, r;
-  load(p, a);
-  load(q, b);
-  te_add(r, p, q);
-  uint32_t w[2 * NW];
-  te_to_affine_canon<F>(w, r);
-  memcpy(out, w, sizeof(w));
-  *oi = 0;
-  return MSMZ_OK;
-}
 
 extern "C" {
 
@@ -227,10 +173,10 @@ int msmz_msm_resident(msmz_ctx* c, uint64_t ph, uint64_t sh, uint64_t n, const m
 int msmz_point_add(int curve_id, const uint8_t* a, int ai, const uint8_t* b, int bi, uint8_t* out, int* oi) {
   if (!out || !oi || (!a && !ai) || (!b && !bi)) return MSMZ_ERR_ARG;
   switch (curve_id) {
-    case MSMZ_BLS12_377_G1: return point_add_w<Bls377Fp>(a, ai, b, bi, out, oi);
-    case MSMZ_PALLAS: return point_add_w<PallasFp>(a, ai, b, bi, out, oi);
-    case MSMZ_BLS12_381_G1: return point_add_w<Bls381Fp>(a, ai, b, bi, out, oi);
-    case MSMZ_ED_ON_BLS12_377: return point_add_te<Ed377Fp>(a, b, out, oi);
+    case MSMZ_BLS12_377_G1: return host_point_add<Bls377Fp, false>(a, ai, b, bi, out, oi);
+    case MSMZ_PALLAS: return host_point_add<PallasFp, false>(a, ai, b, bi, out, oi);
+    case MSMZ_BLS12_381_G1: return host_point_add<Bls381Fp, false>(a, ai, b, bi, out, oi);
+    case MSMZ_ED_ON_BLS12_377: return host_point_add<Ed377Fp, true>(a, 0, b, 0, out, oi);
     default: return MSMZ_ERR_UNSUPPORTED;
   }
 }

@@ -1,0 +1,412 @@
+// Bucket sort of the (window, digit) entries -- rows a2-a5 of SURVEY.md section 8: GLV split, signed-digit
+// slicing, histogram, offsets and the counting-sort scatter (msm-batched-affine.ts:149, 172-200, 411-435, 444-490).
+// Included by kernels.h.
+//
+// The reference copies 116-byte points into bucket order; here only 4-byte references are sorted, and the digits
+// are never written to memory: every pass that needs them recomputes them from the 32-byte scalar.
+//
+//   digit l in [1, L] of window k  ->  bucket index l - 1 = (coarse << FB) | fine,  FB <= FINE_MAX_BITS fine bits
+//   coarse bin id = kw * NCB + coarse     (kw = bucket set: window k, or one of the top window's sub-windows)
+//
+//   k_hist        reads scalars, counts entries per coarse bin (LDS histogram, one global atomic per bin per WG)
+//   k_bin_scan    exclusive scan of the <= 8192 bin counts (one workgroup)
+//   k_coarse      THE bucket scatter: reads scalars again (32 B each), slices all K windows, ranks a tile's entries
+//                 per bin in LDS and writes (fine | negate | index) words in contiguous runs: 32 B in + 4 K B out per
+//                 scalar, nothing else
+//   k_fine        one workgroup per coarse bin (<= 2048 buckets, <= 37888 entries): entries pulled into registers
+//                 with all loads in flight at once, LDS histogram -> bucket offsets `off`, every reference placed at
+//                 its sorted position in LDS, streamed out coalesced; also the largest bucket size
+#pragma once
+
+namespace msmz {
+
+constexpr int COARSE_T = 256;
+constexpr int COARSE_ITEMS = 8;                        // half-scalars (= entries per window) per thread
+constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // entries per window staged by one workgroup
+constexpr int COARSE_MAX_BINS = 512;                   // bins per window (top window: incl. its sub-windows) the staging supports
+constexpr int SORT_MAX_BINS = 8192;                    // all windows: k_coarse keeps 3 words per bin in LDS (96 KB)
+constexpr int FINE_MAX_BITS = 11;
+constexpr int FINE_T = 1024;
+constexpr int FINE_PER = 37;                           // entries a thread holds in registers
+constexpr int FINE_STAGE = FINE_T * FINE_PER;          // 37888 entries staged in LDS: 148 KB + 8 KB of counters (+ static) < 160 KB
+
+struct SortGeom {
+  uint32_t n;          // scalars
+  uint32_t M;          // entries per window: n, or 2 n with GLV (entry n + i = endomorphism half of scalar i)
+  int c, K, fb, spread, idx_bits;
+  uint32_t ncb;        // coarse bins per bucket set = L >> fb
+};
+
+// The (half-)scalars of one input scalar as little-endian words that are shifted down window by window.
+template <class Fr, bool GLV>
+struct DigitStream {
+  static constexpr int HALVES = GLV ? 2 : 1;
+  static constexpr int WORDS = GLV ? 4 : 8;
+  uint32_t w[HALVES][WORDS];
+  uint32_t neg;     // bit h: half h is negative
+  uint32_t carry;   // bit h: carry into the next window of half h
+
+  // returns false when the scalar is not below the group order
+  __device__ __forceinline__ bool load(const uint32_t* scalars, uint32_t i) {
+    uint32_t s[8];
+    const uint4* p4 = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    const uint4 a = p4[0], b = p4[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    carry = 0;
+    if constexpr (GLV) {
+      uint32_t n0, n1;
+      glv_decompose<Fr>(w[0], w[1], n0, n1, s);
+      neg = n0 | (n1 << 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[0][j] = s[j];
+      neg = 0;
+    }
+    return !words_geq<8>(s, Fr::Q);
+  }
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int h = 0; h < HALVES; h++)
+#pragma unroll
+      for (int j = 0; j < WORDS; j++) w[h][j] = 0;
+    neg = carry = 0;
+  }
+  // next signed digit of half h (msm-batched-affine.ts:180-199): returns l in [0, L], sets `ng` to its sign
+  __device__ __forceinline__ uint32_t next(int h, int c, uint32_t L, uint32_t& ng) {
+    uint32_t l = (w[h][0] & ((1u << c) - 1u)) + ((carry >> h) & 1u);
+#pragma unroll
+    for (int j = 0; j < WORDS - 1; j++) w[h][j] = __builtin_amdgcn_alignbit(w[h][j + 1], w[h][j], (uint32_t)c);
+    w[h][WORDS - 1] >>= c;
+    uint32_t cy = 0;
+    if (l > L) {
+      l = 2 * L - l;
+      cy = 1;
+    }
+    carry = (carry & ~(1u << h)) | (cy << h);
+    ng = (cy ^ (neg >> h)) & (l != 0 ? 1u : 0u);   // the half scalar's own sign flips every digit's sign
+    return l;
+  }
+};
+
+// counter[key] += 1, returning the old value.  (Measured: matching equal keys across the wave with ballots so that one
+// lane per key issues the LDS atomic costs ~80 VALU instructions per wave instruction and made k_hist 2.2x and
+// k_coarse 1.5x SLOWER than plain per-lane LDS atomics, which cost ~24 LDS cycles per wave instruction here.)
+__device__ __forceinline__ uint32_t counter_add(uint32_t* counter, uint32_t key, bool active) {
+  return active ? atomicAdd(&counter[key], 1u) : 0u;
+}
+
+// bucket set (window, or sub-window of the sparse top window) and coarse bin of a non-zero digit
+__device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_t l, uint32_t entry) {
+  uint32_t kw = (uint32_t)k;
+  if (k == g.K - 1) kw += entry & ((1u << g.spread) - 1u);
+  return kw * g.ncb + ((l - 1) >> g.fb);
+}
+
+// ------------------------------------------------------------------------------------------------ histogram
+// counts[bin] += entries; meta->error |= 2 when a scalar does not fit K windows (a GLV half above the assumed
+// bound: the host then repeats the MSM with one more bit), |= 4 when a scalar is not below the group order
+// (scalarsFromBytes' precondition, checked here instead of in a serial host loop).
+template <class Fr, bool GLV>
+__global__ void __launch_bounds__(256) k_hist(uint32_t* counts, MsmMeta* meta, const uint32_t* scalars, SortGeom g,
+                                              uint32_t nbins) {
+  extern __shared__ uint32_t s_hist[];
+  constexpr int HALVES = GLV ? 2 : 1;
+  constexpr int PER = 8;   // scalars per thread
+  const uint32_t L = 1u << (g.c - 1);
+  for (uint32_t b = threadIdx.x; b < nbins; b += 256) s_hist[b] = 0;
+  __syncthreads();
+  uint32_t overflow = 0;
+#pragma unroll 1
+  for (int it = 0; it < PER; it++) {
+    const uint32_t i = (blockIdx.x * PER + it) * 256 + threadIdx.x;
+    const bool live = i < g.n;
+    DigitStream<Fr, GLV> ds;
+    if (live) {
+      if (!ds.load(scalars, i)) overflow |= 0x80000000u;
+    } else {
+      ds.clear();
+    }
+#pragma unroll 1
+    for (int k = 0; k < g.K; k++) {
+#pragma unroll
+      for (int h = 0; h < HALVES; h++) {
+        uint32_t ng;
+        const uint32_t l = ds.next(h, g.c, L, ng);
+        const uint32_t bin = l != 0 ? coarse_bin(g, k, l, (uint32_t)h * g.n + i) : 0u;
+        (void)counter_add(s_hist, bin, l != 0);
+      }
+    }
+    overflow |= ds.carry & 3u;
+#pragma unroll
+    for (int h = 0; h < HALVES; h++)
+#pragma unroll
+      for (int j = 0; j < DigitStream<Fr, GLV>::WORDS; j++) overflow |= ds.w[h][j] != 0 ? 1u : 0u;   // bits beyond the last window
+  }
+  if (overflow & 0x80000000u) atomicOr(&meta->error, 4u);
+  if (overflow & 0x7fffffffu) atomicOr(&meta->error, 2u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
+    const uint32_t v = s_hist[b];
+    if (v) atomicAdd(&counts[b], v);
+  }
+}
+
+// exclusive scan of nbins <= SORT_MAX_BINS counts by one workgroup; base[nbins] = total = number of entries
+static __global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* base, const uint32_t* counts, uint32_t nbins,
+                                                          uint32_t* total_out) {
+  __shared__ uint32_t s_wave[16];
+  constexpr int PER = SORT_MAX_BINS / 1024;
+  uint32_t v[PER], sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const uint32_t b = threadIdx.x * PER + j;
+    v[j] = b < nbins ? counts[b] : 0;
+    sum += v[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  uint32_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < 16; w2++) {
+    const uint32_t t = s_wave[w2];
+    if (w2 < wave) wbase += t;
+    tot += t;
+  }
+  uint32_t ex = wbase + x - sum;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const uint32_t b = threadIdx.x * PER + j;
+    if (b < nbins) base[b] = ex;
+    ex += v[j];
+  }
+  if (threadIdx.x == 0) {
+    base[nbins] = tot;
+    *total_out = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ coarse scatter
+// One tile = COARSE_TILE half-scalars (2048 scalars, or 1024 scalars with GLV).
+//   phase A  all K windows are sliced once just to count the tile's entries per bin (LDS atomics); then
+//            every bin's run is reserved in global memory with one atomic per bin -- all of them in flight together,
+//            ONE global-atomic latency per workgroup instead of one per window -- and a block scan turns the counts
+//            into staging offsets;
+//   phase B  window by window: slice again, rank the entries per bin (LDS atomics), stage them in LDS in bin
+//            order, write every bin's entries as one contiguous run.  Double-buffered staging: 2 barriers per window.
+// Algorithmic HBM bytes: 32 B read per scalar + 4 B written per entry.  Dynamic LDS: 3 * nbins words.
+template <class Fr, bool GLV>
+__global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint32_t* bin_cursor, const uint32_t* bin_base,
+                                                     const uint32_t* scalars, SortGeom g, uint32_t nbins) {
+  constexpr int HALVES = GLV ? 2 : 1;
+  constexpr int SC = COARSE_ITEMS / HALVES;           // scalars per thread
+  extern __shared__ uint32_t s_dyn[];
+  uint32_t* s_off = s_dyn;                  // [nbins] counts, then offsets inside the window's staging order
+  uint32_t* s_cur = s_dyn + nbins;          // [nbins] running rank counters of phase B
+  uint32_t* s_gbase = s_dyn + 2 * nbins;    // [nbins] global address of this tile's run in each bin
+  __shared__ uint32_t s_stage[2][COARSE_TILE];
+  __shared__ uint32_t s_wave[COARSE_T / 64];
+  const uint32_t L = 1u << (g.c - 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t fmask = (1u << g.fb) - 1u;
+
+  DigitStream<Fr, GLV> ds[SC];
+  uint32_t idx[SC];
+#pragma unroll
+  for (int s = 0; s < SC; s++) {
+    idx[s] = (blockIdx.x * SC + s) * COARSE_T + threadIdx.x;
+    if (idx[s] < g.n) ds[s].load(scalars, idx[s]); else ds[s].clear();
+  }
+  for (uint32_t b = threadIdx.x; b < nbins; b += COARSE_T) {
+    s_off[b] = 0;
+    s_cur[b] = 0;
+  }
+  __syncthreads();
+  // ---------------- phase A: counts of all windows
+  {
+    DigitStream<Fr, GLV> dc[SC];
+#pragma unroll
+    for (int s = 0; s < SC; s++) dc[s] = ds[s];
+#pragma unroll 1
+    for (int k = 0; k < g.K; k++) {
+      const bool top = k == g.K - 1;
+      const uint32_t smask = top ? (1u << g.spread) - 1u : 0u;
+#pragma unroll
+      for (int s = 0; s < SC; s++) {
+#pragma unroll
+        for (int h = 0; h < HALVES; h++) {
+          uint32_t ng;
+          const uint32_t l = dc[s].next(h, g.c, L, ng);
+          const uint32_t entry = (uint32_t)h * g.n + idx[s];
+          const uint32_t bin = l != 0 ? (entry & smask) * g.ncb + ((l - 1) >> g.fb) : 0u;
+          (void)counter_add(s_off + (uint32_t)k * g.ncb, bin, l != 0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // reserve the runs (all bins at once), scan the counts: offset of a bin inside ITS window's staging order
+  {
+    const uint32_t per = (nbins + COARSE_T - 1) / COARSE_T;   // consecutive bins per thread
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t b = b0 + q;
+      if (b < nbins) {
+        const uint32_t cnt = s_off[b];
+        s_gbase[b] = cnt ? bin_base[b] + atomicAdd(&bin_cursor[b], cnt) : 0u;
+        sum += cnt;
+      }
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(sum, &total, s_wave);
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t b = b0 + q;
+      if (b < nbins) {
+        const uint32_t cnt = s_off[b];
+        s_off[b] = ex;          // still relative to the tile's first entry: the window start is subtracted below
+        ex += cnt;
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- phase B: window by window
+#pragma unroll 1
+  for (int k = 0; k < g.K; k++) {
+    const int buf = k & 1;
+    const bool top = k == g.K - 1;
+    const uint32_t smask = top ? (1u << g.spread) - 1u : 0u;
+    const uint32_t ncbk = top ? g.ncb << g.spread : g.ncb;   // bins of this window (its sub-windows follow each other)
+    const uint32_t* off_k = s_off + (uint32_t)k * g.ncb;
+    const uint32_t wbase = off_k[0];
+#pragma unroll
+    for (int s = 0; s < SC; s++) {
+#pragma unroll
+      for (int h = 0; h < HALVES; h++) {
+        uint32_t ng;
+        const uint32_t l = ds[s].next(h, g.c, L, ng);
+        const uint32_t entry = (uint32_t)h * g.n + idx[s];
+        const uint32_t bi = l - 1;
+        const uint32_t bin = l != 0 ? (entry & smask) * g.ncb + (bi >> g.fb) : 0u;
+        const uint32_t rank = counter_add(s_cur + (uint32_t)k * g.ncb, bin, l != 0);
+        if (l != 0)
+          s_stage[buf][off_k[bin] - wbase + rank] = ((bi & fmask) << (g.idx_bits + 1)) | (ng << g.idx_bits) | entry;
+      }
+    }
+    __syncthreads();
+    // one wave per bin: each run is a contiguous, coalesced store.  The next window stages into the other buffer;
+    // the barrier of the window after that orders this buffer's reuse behind these reads.
+    for (uint32_t b = wave; b < ncbk; b += COARSE_T / 64) {
+      const uint32_t gb = (uint32_t)k * g.ncb + b;
+      const uint32_t r0 = s_off[gb] - wbase, r1 = r0 + s_cur[gb];   // s_cur[gb] = the bin's entry count by now
+      const uint32_t gaddr = s_gbase[gb];
+      for (uint32_t p = r0 + lane; p < r1; p += 64) packed_out[gaddr + (p - r0)] = s_stage[buf][p];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fine sort
+// `n_half` / `endo_delta`: with GLV the entry index i >= n_half is the endomorphism half of point i - n_half; its
+// record sits at index i + endo_delta of the point set (the images follow the whole set, which may be larger than
+// the prefix this MSM covers: msm-batched-affine.ts:74-97 takes any N <= allocated).
+template <bool STAGE>
+__global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
+                                                 const uint32_t* packed, const uint32_t* bin_base, int fb,
+                                                 uint32_t n_bins, int idx_bits, uint32_t n_half, uint32_t endo_delta) {
+  extern __shared__ uint32_t s_dyn[];
+  uint32_t* s_cnt = s_dyn;                                  // [1 << FINE_MAX_BITS] counts, then running cursors
+  uint32_t* s_stage = s_dyn + (1 << FINE_MAX_BITS);          // [FINE_STAGE]
+  __shared__ uint32_t s_wave[FINE_T / 64];
+  const uint32_t bin = blockIdx.x;
+  const uint32_t nfine = 1u << fb;
+  const uint32_t per = (nfine + FINE_T - 1) / FINE_T;        // consecutive buckets per thread (<= 2)
+  const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
+  const uint32_t cnt_bin = end - begin;
+  const bool staged = cnt_bin <= (uint32_t)FINE_STAGE;   // the bin fits the threads' registers (and the LDS staging)
+  const uint32_t imask = (1u << idx_bits) - 1u;
+  for (uint32_t f = threadIdx.x; f < nfine; f += FINE_T) s_cnt[f] = 0;
+  // the bin's entries: all loads of a thread are issued back to back (the bin is read ONCE)
+  uint32_t v[FINE_PER];
+  if (staged) {
+#pragma unroll
+    for (int j = 0; j < FINE_PER; j++) {
+      const uint32_t p = (uint32_t)j * FINE_T + threadIdx.x;
+      v[j] = p < cnt_bin ? packed[begin + p] : 0u;
+    }
+  }
+  __syncthreads();
+  if (staged) {
+#pragma unroll
+    for (int j = 0; j < FINE_PER; j++)
+      if ((uint32_t)j * FINE_T + threadIdx.x < cnt_bin) atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
+  } else {
+    for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t mine = 0, mx = 0, cnts[2] = {0, 0};
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t f = threadIdx.x * per + j;
+    const uint32_t c = f < nfine ? s_cnt[f] : 0;
+    cnts[j & 1] = c;
+    mine += c;
+    mx = c > mx ? c : mx;
+  }
+  // block-wide exclusive scan of `mine` over FINE_T threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w2 = 0; w2 < wave; w2++) wbase += s_wave[w2];
+  uint32_t ex = wbase + x - mine;                            // relative to the bin start
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t f = threadIdx.x * per + j;
+    if (f < nfine) {
+      s_cnt[f] = ex;                                         // becomes the running cursor of bucket f
+      off[(size_t)bin * nfine + f] = begin + ex;
+      ex += cnts[j & 1];
+    }
+  }
+  if (mx > 1) atomicMax(max_bucket, mx);
+  if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
+  __syncthreads();
+  auto to_ref = [&](uint32_t pv) {
+    uint32_t idx = pv & imask;
+    if (idx >= n_half) idx += endo_delta;   // endomorphism half: record index in the point set
+    return idx | (((pv >> idx_bits) & 1u) << 31);
+  };
+  if (staged) {
+#pragma unroll
+    for (int j = 0; j < FINE_PER; j++) {
+      if ((uint32_t)j * FINE_T + threadIdx.x < cnt_bin) {
+        const uint32_t pos = atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
+        if (STAGE) s_stage[pos] = to_ref(v[j]); else refs[begin + pos] = to_ref(v[j]);
+      }
+    }
+    if (STAGE) {
+      __syncthreads();
+      for (uint32_t p = threadIdx.x; p < cnt_bin; p += FINE_T) refs[begin + p] = s_stage[p];
+    }
+  } else {
+    // a bin too large for the LDS staging (heavily repeated scalars): second read, scattered stores
+    for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) {
+      const uint32_t pv = packed[p];
+      const uint32_t pos = atomicAdd(&s_cnt[pv >> (idx_bits + 1)], 1u);
+      refs[begin + pos] = to_ref(pv);
+    }
+  }
+}
+
+}  // namespace msmz
