@@ -14,8 +14,7 @@ LIB = os.path.join(HERE, "libmsmz.so")
 SOURCES = ["msmz.hip", "kern_batch.hip", "kern_reduce.hip", "kern_misc.hip", "kern_gen.hip"]
 # (source, curve id) translation units; curve 3 (twisted Edwards) has no batched-affine kernels
 UNITS = [("msmz.hip", None)] + [(f, c) for c in (0, 1, 2, 3) for f in SOURCES[1:] if not (f == "kern_batch.hip" and c == 3)]
-HEADERS = ["fp.h", "fp_cios.h", "curve.h", "scalar.h", "kernels.h", "gen_kernels.h", "engine.h", "constants_gen.h",
-           "instantiate.h", "host64.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))   # every header: a change to any of them rebuilds
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value"]
 
 

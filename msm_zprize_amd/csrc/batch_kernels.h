@@ -24,6 +24,13 @@ namespace msmz {
 #ifndef MSMZ_BATCH_BMAX
 #define MSMZ_BATCH_BMAX 32
 #endif
+#ifdef MSMZ_EXP_NOMUL   // timing experiment (wrong results): the six products of an addition cost nothing
+#define BM_MUL(r, a, b) fe_add(r, a, b)
+#define BM_SQR(r, a) fe_add(r, a, a)
+#else
+#define BM_MUL(r, a, b) fe_mul(r, a, b)
+#define BM_SQR(r, a) fe_sqr(r, a)
+#endif
 enum { PK_NONE = 0, PK_ADD = 1, PK_DBL = 2, PK_TAKE_A = 3, PK_TAKE_B = 4, PK_INF = 5 };
 
 template <class F, int T, bool SAFE, int OCC, int BMAX>
@@ -42,13 +49,17 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   Fe<F> prefix;
   fe_set_const<F>(prefix, F::ONE);
   // ---------------------------------------------------------------- forward pass
+  // (the next pair's descriptor is requested one iteration ahead: operand addresses never wait for it)
+  uint2 dnext = make_uint2(0, 0);
+  if (block_base + threadIdx.x < total) dnext = dsc[block_base + threadIdx.x];
 #pragma unroll 1
   for (int i = 0; i < B; i++) {
     const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
     uint32_t kind = PK_NONE;
+    uint2 dd = dnext;
+    if (i + 1 < B && t + (uint32_t)T < total) dnext = dsc[t + (uint32_t)T];
     if (t < total) {
-      uint2 dd = dsc[t];
-#ifdef MSMZ_EXP_LOCALMEM   // timing experiment (wrong results): every operand from a small cache-resident set
+#if defined(MSMZ_EXP_LOCALMEM) || defined(MSMZ_EXP_LOCAL_FWD)   // timing experiment (wrong results): every operand from a small cache-resident set
       dd.x = LOC_ORIG | (t & 4095u);
       dd.y = LOC_ORIG | ((t + 1u) & 4095u);
 #endif
@@ -81,14 +92,14 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       if (kind == PK_ADD || kind == PK_DBL) {
         // park z = prefix * numerator in the pair's output record (a product's limbs are valid inputs as they are)
         Fe<F> z;
-        fe_mul(z, prefix, num);
-#ifdef MSMZ_EXP_LOCALMEM
-        slot_store_fe<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), z);
+        BM_MUL(z, prefix, num);
+#if defined(MSMZ_EXP_LOCALMEM) || defined(MSMZ_EXP_LOCAL_Z)
+        slot_store_mulout<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), z);
 #else
-        slot_store_fe<F>(slots + slot_offset<F>(out_base + t), z);
+        slot_store_mulout<F>(slots + slot_offset<F>(out_base + t), z);
 #endif
         Fe<F> np;
-        fe_mul(np, prefix, d);
+        BM_MUL(np, prefix, d);
         prefix = np;
       }
     }
@@ -176,15 +187,22 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   }
 
   // ---------------------------------------------------------------- backward pass
+  {
+    const uint32_t tl = block_base + (uint32_t)(B - 1) * T + threadIdx.x;
+    if (tl < total) dnext = dsc[tl];
+  }
 #pragma unroll 1
   for (int i = B - 1; i >= 0; i--) {
     const uint32_t t = block_base + (uint32_t)i * T + threadIdx.x;
+    uint2 dd = dnext;
+    if (i > 0 && t - (uint32_t)T < total) dnext = dsc[t - (uint32_t)T];
     if (t >= total) continue;
     const uint32_t kind = SAFE ? s_kind[i * T + threadIdx.x] : (uint32_t)PK_ADD;
-    uint2 dd = dsc[t];
-#ifdef MSMZ_EXP_LOCALMEM
+#if defined(MSMZ_EXP_LOCALMEM) || defined(MSMZ_EXP_LOCAL_BWD)
     dd.x = LOC_ORIG | (t & 4095u);
     dd.y = LOC_ORIG | ((t + 1u) & 4095u);
+#endif
+#if defined(MSMZ_EXP_LOCALMEM) || defined(MSMZ_EXP_LOCAL_Z)
     uint32_t* out = slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u));
 #else
     uint32_t* out = slots + slot_offset<F>(out_base + t);
@@ -203,15 +221,15 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
         fe_add(d, p2.y, p2.y);
         fe_add(s12, p2.x, p2.x);
       }
-      fe_mul(mm, z, run);                 // slope
-      fe_mul(tt, run, d);
+      BM_MUL(mm, z, run);                 // slope
+      BM_MUL(tt, run, d);
       run = tt;
-      fe_sqr(ms, mm);
+      BM_SQR(ms, mm);
       Affine<F> res;
       fe_sub(res.x, ms, s12);             // x3 = m^2 - x1 - x2
       fe_sub(tt, p2.x, res.x);
       fe_carry(tt);
-      fe_mul(ms, mm, tt);
+      BM_MUL(ms, mm, tt);
       fe_sub(res.y, ms, p2.y);            // y3 = m (x2 - x3) - y2
       slot_store_point<F>(out, res, false);
     } else if (kind == PK_TAKE_A || kind == PK_TAKE_B) {

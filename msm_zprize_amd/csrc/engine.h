@@ -162,7 +162,7 @@ class Engine : public IEngine {
   ~Engine() override {
     (void)hipSetDevice(device_);
     for (auto& kv : handles_) (void)hipFree(kv.second.dev);
-    for (DevBuf* b : {&desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+    for (DevBuf* b : {&tilecnt_, &final_, &desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
                       &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
       b->release();
     if (h_meta_) (void)hipHostFree(h_meta_);
@@ -540,16 +540,16 @@ class Engine : public IEngine {
       MSMZ_HIP(hipMemsetAsync(d_counts, 0, (size_t)2 * nbins * 4, stream_));
       SortGeom g{n, M, c, K, fb, pl.spread, idx_bits, ncb};
       mark(pl);  // 0
-      {
-        const uint32_t grid = (n + 256 * 8 - 1) / (256 * 8);
-        if (pl.glv) {
-          if constexpr (Fr::HAS_GLV)
-            hipLaunchKernelGGL((k_hist<Fr, true>), dim3(grid), dim3(256), (size_t)nbins * 4, stream_, d_counts, d_meta,
-                               d_scalars, g, nbins);
-        } else {
-          hipLaunchKernelGGL((k_hist<Fr, false>), dim3(grid), dim3(256), (size_t)nbins * 4, stream_, d_counts, d_meta,
-                             d_scalars, g, nbins);
-        }
+      const uint32_t per_tile = pl.glv ? COARSE_TILE / 2 : COARSE_TILE;   // scalars per workgroup (k_hist and k_coarse)
+      const uint32_t tiles = (n + per_tile - 1) / per_tile;
+      if ((st = tilecnt_.ensure((size_t)tiles * nbins * 2))) return st;
+      if (pl.glv) {
+        if constexpr (Fr::HAS_GLV)
+          hipLaunchKernelGGL((k_hist<Fr, true>), dim3(tiles), dim3(256), (size_t)nbins * 4, stream_, d_counts,
+                             tilecnt_.as<uint16_t>(), d_meta, d_scalars, g, nbins);
+      } else {
+        hipLaunchKernelGGL((k_hist<Fr, false>), dim3(tiles), dim3(256), (size_t)nbins * 4, stream_, d_counts,
+                           tilecnt_.as<uint16_t>(), d_meta, d_scalars, g, nbins);
       }
       mark(pl);  // 1
       MSMZ_HIP(hipGetLastError());
@@ -558,19 +558,18 @@ class Engine : public IEngine {
       mark(pl);  // 2
       MSMZ_HIP(hipGetLastError());
       {
-        const uint32_t per_tile = pl.glv ? COARSE_TILE / 2 : COARSE_TILE;   // scalars per workgroup
-        const uint32_t grid = (n + per_tile - 1) / per_tile;
+        const uint32_t grid = tiles;
         const size_t lds = (size_t)3 * nbins * 4;
         if (pl.glv) {
           if constexpr (Fr::HAS_GLV) {
             if (lds > 32768) MSMZ_HIP(hipFuncSetAttribute((const void*)k_coarse<Fr, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_coarse<Fr, true>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
-                               d_cursor, bins_.as<uint32_t>(), d_scalars, g, nbins);
+                               d_cursor, bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
           }
         } else {
           if (lds > 32768) MSMZ_HIP(hipFuncSetAttribute((const void*)k_coarse<Fr, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           hipLaunchKernelGGL((k_coarse<Fr, false>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
-                             d_cursor, bins_.as<uint32_t>(), d_scalars, g, nbins);
+                             d_cursor, bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
         }
       }
       pl.ev_coarse = pl.ei;
@@ -655,7 +654,7 @@ class Engine : public IEngine {
   int reduce_levels(const Plan& pl, int& cur, uint32_t n_in) {
     constexpr int AW = P::ACC_WORDS;
     int st;
-    while (n_in > 1) {
+    while (n_in > REDUCE_TAIL_N) {
       const uint32_t S = 4;   // quads handle short tails too
       uint32_t g2 = (n_in + S - 1) / S;
       int nxt = cur ^ 1;
@@ -675,6 +674,17 @@ class Engine : public IEngine {
       n_in = g2;
       cur = nxt;
     }
+    // the last levels (<= REDUCE_TAIL_N entries per window) in ONE launch, one workgroup per window; leaves the
+    // window sums in final_
+    {
+      const int nxt = cur ^ 1;
+      if ((st = red_[nxt * 2].ensure((size_t)pl.Keff * n_in * AW * 4))) return st;
+      if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.Keff * n_in * AW * 4))) return st;
+      if ((st = final_.ensure((size_t)pl.Keff * AW * 4))) return st;
+      hipLaunchKernelGGL((k_reduce_tail<P>), dim3(pl.Keff), dim3(REDUCE_TAIL_T), 0, stream_, red_[cur * 2].as<uint32_t>(),
+                         red_[cur * 2 + 1].as<uint32_t>(), red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
+                         final_.as<uint32_t>(), n_in, n_in);
+    }
     return MSMZ_OK;
   }
 
@@ -693,7 +703,8 @@ class Engine : public IEngine {
   int fetch_window_sums(const Plan& pl, int cur) {
     constexpr int AW = P::ACC_WORDS;
     MSMZ_HIP(hipGetLastError());
-    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, red_[cur * 2 + 1].p, (size_t)pl.Keff * AW * 4,
+    (void)cur;
+    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, final_.p, (size_t)pl.Keff * AW * 4,
                             hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipMemcpyAsync(h_meta_, meta_.p, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
@@ -1065,7 +1076,7 @@ class Engine : public IEngine {
   int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
   bool fine_attr_set_ = false;
   bool fine_stage_ = env_int("MSMZ_FINE_STAGE", 1) != 0;   // unstaged (scattered 4-byte stores): measured 277 vs 148 us
-  DevBuf desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  DevBuf tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};
   int basic_ev_[4] = {};

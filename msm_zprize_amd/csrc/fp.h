@@ -136,13 +136,17 @@ MSMZ_HD void fe_mul(Fe<F>& r, const Fe<F>& a_in, const Fe<F>& b_in) {
   for (int k = 0; k < 2 * N - 1; k++) {
     const int lo = k - (N - 1) > 0 ? k - (N - 1) : 0;
     const int hi = k < N - 1 ? k : N - 1;
+    // two independent accumulation chains per column (a*b terms / m*p terms): a kernel that runs one or two waves per
+    // SIMD (the reduction levels) is bound by the latency of back-to-back dependent v_mad_i64_i32
+    int64_t accp = 0;
 #pragma unroll
     for (int i = lo; i <= hi; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       const int j = k - i;
-      if (j >= 1 && F::PL[j] != 0) acc += (int64_t)m[i] * (int64_t)F::NPL[j];
+      if (j >= 1 && F::PL[j] != 0) accp += (int64_t)m[i] * (int64_t)F::NPL[j];
     }
+    acc += accp;
     if (k < N) {
       uint32_t q = (uint32_t)acc;
       if (F::PINV != 1u) q *= F::PINV;
@@ -182,13 +186,14 @@ MSMZ_HD void fe_sqr(Fe<F>& r, const Fe<F>& a_in) {
       const int j = k - i;
       if (i < j) off += (int64_t)a.l[i] * (int64_t)a.l[j];
     }
-    acc += off * 2;
-    if ((k & 1) == 0) acc += (int64_t)a.l[k / 2] * (int64_t)a.l[k / 2];
+    int64_t accp = 0;
+    if ((k & 1) == 0) accp = (int64_t)a.l[k / 2] * (int64_t)a.l[k / 2];
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       const int j = k - i;
-      if (j >= 1 && F::PL[j] != 0) acc += (int64_t)m[i] * (int64_t)F::NPL[j];
+      if (j >= 1 && F::PL[j] != 0) accp += (int64_t)m[i] * (int64_t)F::NPL[j];
     }
+    acc += off * 2 + accp;
     if (k < N) {
       uint32_t q = (uint32_t)acc;
       if (F::PINV != 1u) q *= F::PINV;

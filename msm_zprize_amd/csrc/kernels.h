@@ -104,20 +104,28 @@ __device__ __forceinline__ void store_affine(uint32_t* rec, const Affine<F>& p, 
   store_words<F, NT>(rec, w, cs);
 }
 
-// Slot arrays (results of the tree rounds) hold affine points in LIMB form: the N signed limbs of x, then the N limbs
-// of y, one 32-bit word each (28 words for the 377/381-bit fields, 18 -> padded to 20 for the 255-bit ones), values
-// reduced to [0, 3p) with normalized limbs; the all-zero record is the point at infinity.  Nothing is packed or
-// unpacked on the way between two tree rounds (that cost ~480 of ~4300 instructions per addition).
+// Slot arrays (results of the tree rounds) hold affine points [x | y], values reduced to [0, 3p); the all-zero
+// record is the point at infinity.  Two record formats (MSMZ_SLOT_PACKED):
+//   packed (default)  2*NW saturated words like the resident points (96 / 64 bytes)
+//   limb form         the N signed limbs of x, then of y, one word each (112 / 80 bytes): nothing to pack or unpack
+//                     between two tree rounds (~400 instructions per addition) but 17-25 % more bytes
+// The tree rounds are bound by memory traffic (measured: 2.3 ms with the field products removed, 1.85 ms with every
+// operand served from cache), so the smaller record wins.
 // The arrays are chunk-interleaved in groups of 64 records: chunk q (16 bytes) of record r sits at 16-byte unit
 // (r / 64) * 64 * CH + q * 64 + r % 64, CH = chunks per record.  A wave whose lanes hold consecutive records (the
 // writers) then moves one contiguous KB per load/store instruction, and the readers of the next round (lane i wants
 // records 2i, 2i + 1) two KB, instead of 64 pieces a record apart.
+#ifndef MSMZ_SLOT_PACKED
+#define MSMZ_SLOT_PACKED 1
+#endif
 constexpr int SLOT_CS = 64;
 template <class F>
 struct SlotFmt {
-  static constexpr int WORDS = (2 * F::N + 3) / 4 * 4;   // words per record
-  static constexpr int CH = WORDS / 4;                   // 16-byte chunks per record
-  static constexpr int XCH = (F::N + 3) / 4;             // chunks that cover x (and, padded, a parked field element)
+  static constexpr bool PACKED = MSMZ_SLOT_PACKED != 0;
+  static constexpr int FE_WORDS = PACKED ? F::NW : F::N;                  // words of one coordinate
+  static constexpr int WORDS = PACKED ? 2 * F::NW : (2 * F::N + 3) / 4 * 4;   // words per record
+  static constexpr int CH = WORDS / 4;                                    // 16-byte chunks per record
+  static constexpr int XCH = (FE_WORDS + 3) / 4;                          // chunks that cover x (or a parked field element)
 };
 template <class F>
 __device__ __forceinline__ size_t slot_offset(uint32_t rec) {   // in 32-bit words
@@ -150,42 +158,75 @@ __device__ __forceinline__ void slot_store_chunks(uint32_t* rec, const uint32_t*
 // whole record; returns true if it is the point at infinity (only evaluated when CHECK_INF)
 template <class F, bool CHECK_INF>
 __device__ __forceinline__ bool slot_load_point(Affine<F>& p, const uint32_t* rec) {
-  uint32_t w[SlotFmt<F>::WORDS];
-  slot_load_chunks<SlotFmt<F>::CH>(w, rec);
+  using S = SlotFmt<F>;
+  uint32_t w[S::WORDS];
+  slot_load_chunks<S::CH>(w, rec);
   uint32_t o = 0;
+  if (CHECK_INF) {
 #pragma unroll
-  for (int j = 0; j < F::N; j++) {
-    p.x.l[j] = (int32_t)w[j];
-    p.y.l[j] = (int32_t)w[F::N + j];
-    if (CHECK_INF) o |= w[j] | w[F::N + j];
+    for (int j = 0; j < 2 * S::FE_WORDS; j++) o |= w[j];
+  }
+  if constexpr (S::PACKED) {
+    fe_unpack<F>(p.x, w);
+    fe_unpack<F>(p.y, w + F::NW);
+  } else {
+#pragma unroll
+    for (int j = 0; j < F::N; j++) {
+      p.x.l[j] = (int32_t)w[j];
+      p.y.l[j] = (int32_t)w[F::N + j];
+    }
   }
   return CHECK_INF && o == 0;
 }
+// the x coordinate of a point record / a parked field element
 template <class F>
-__device__ __forceinline__ void slot_load_fe(Fe<F>& x, const uint32_t* rec) {   // the x limbs / a parked element
-  uint32_t w[SlotFmt<F>::XCH * 4];
-  slot_load_chunks<SlotFmt<F>::XCH>(w, rec);
+__device__ __forceinline__ void slot_load_fe(Fe<F>& x, const uint32_t* rec) {
+  using S = SlotFmt<F>;
+  uint32_t w[S::XCH * 4];
+  slot_load_chunks<S::XCH>(w, rec);
+  if constexpr (S::PACKED) {
+    fe_unpack<F>(x, w);
+  } else {
 #pragma unroll
-  for (int j = 0; j < F::N; j++) x.l[j] = (int32_t)w[j];
+    for (int j = 0; j < F::N; j++) x.l[j] = (int32_t)w[j];
+  }
 }
+// park a direct mul/sqr output (value in (-1.5p, 0.5p), normalized limbs with a signed top limb)
 template <class F>
-__device__ __forceinline__ void slot_store_fe(uint32_t* rec, const Fe<F>& x) {
-  uint32_t w[SlotFmt<F>::XCH * 4];
+__device__ __forceinline__ void slot_store_mulout(uint32_t* rec, const Fe<F>& x) {
+  using S = SlotFmt<F>;
+  uint32_t w[S::XCH * 4];
+  if constexpr (S::PACKED) {
+    fe_store_mulout<F>(w, x);
 #pragma unroll
-  for (int j = 0; j < SlotFmt<F>::XCH * 4; j++) w[j] = j < F::N ? (uint32_t)x.l[j] : 0u;
-  slot_store_chunks<SlotFmt<F>::XCH>(rec, w);
+    for (int j = F::NW; j < S::XCH * 4; j++) w[j] = 0;
+  } else {
+#pragma unroll
+    for (int j = 0; j < S::XCH * 4; j++) w[j] = j < F::N ? (uint32_t)x.l[j] : 0u;
+  }
+  slot_store_chunks<S::XCH>(rec, w);
 }
-// x, y: any lazy values |v| < 2^4 p; stored reduced to [0, 3p) with normalized limbs
+// x, y: any lazy values |v| < 2^4 p; stored reduced to [0, 3p)
 template <class F>
 __device__ __forceinline__ void slot_store_point(uint32_t* rec, const Affine<F>& p, bool inf) {
-  uint32_t w[SlotFmt<F>::WORDS];
-  Fe<F> x = p.x, y = p.y;
-  fe_reduce_small(x);
-  fe_reduce_small(y);
+  using S = SlotFmt<F>;
+  uint32_t w[S::WORDS];
+  if constexpr (S::PACKED) {
+    fe_store<F>(w, p.x);
+    fe_store<F>(w + F::NW, p.y);
+  } else {
+    Fe<F> x = p.x, y = p.y;
+    fe_reduce_small(x);
+    fe_reduce_small(y);
 #pragma unroll
-  for (int j = 0; j < SlotFmt<F>::WORDS; j++)
-    w[j] = inf ? 0u : (j < F::N ? (uint32_t)x.l[j] : (j < 2 * F::N ? (uint32_t)y.l[j - F::N] : 0u));
-  slot_store_chunks<SlotFmt<F>::CH>(rec, w);
+    for (int j = 0; j < S::WORDS; j++)
+      w[j] = j < F::N ? (uint32_t)x.l[j] : (j < 2 * F::N ? (uint32_t)y.l[j - F::N] : 0u);
+  }
+  if (inf) {
+#pragma unroll
+    for (int j = 0; j < S::WORDS; j++) w[j] = 0;
+  }
+  slot_store_chunks<S::CH>(rec, w);
 }
 
 template <class F>
@@ -479,12 +520,27 @@ namespace msmz {
 
 // ------------------------------------------------------------------------------------------------ operands
 // A location word (plan_kernels.h) names an operand of a tree round / a partial bucket sum: an original point
-// (bit 30; bit 31 = negate; packed record in the resident point set) or a slot record (limb form).
+// (bit 30; bit 31 = negate; record in the resident point set) or a slot record.  With packed slot records both are
+// 2*NW saturated words and differ only in where their 16-byte chunks sit (contiguous / chunk-interleaved), so an
+// operand is loaded WITHOUT a branch on its kind: all loads of a pair are issued back to back and cost one memory
+// latency, not one per operand.
+template <class F>
+__device__ __forceinline__ const uint32_t* operand_address(uint32_t loc, const uint32_t* slots, const uint32_t* points,
+                                                            int& cs, uint32_t& neg) {
+  const bool orig = (loc & LOC_ORIG) != 0;
+  cs = orig ? 1 : SLOT_CS;
+  neg = orig ? loc >> 31 : 0u;
+  return orig ? points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW) : slots + slot_offset<F>(loc);
+}
+
 template <class F, bool CHECK_INF>
 __device__ __forceinline__ bool load_operand(Affine<F>& p, uint32_t loc, const uint32_t* slots, const uint32_t* points) {
-  if (loc & LOC_ORIG) {
+  if constexpr (SlotFmt<F>::PACKED) {
+    int cs;
+    uint32_t neg;
+    const uint32_t* rec = operand_address<F>(loc, slots, points, cs, neg);
     uint32_t w[2 * F::NW];
-    load_words<F>(w, points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
+    load_words<F>(w, rec, cs);
     uint32_t o = 0;
     if (CHECK_INF) {
 #pragma unroll
@@ -493,20 +549,37 @@ __device__ __forceinline__ bool load_operand(Affine<F>& p, uint32_t loc, const u
     fe_unpack<F>(p.x, w);
     Fe<F> y;
     fe_unpack<F>(y, w + F::NW);
-    fe_cneg(p.y, y, loc >> 31);
+    fe_cneg(p.y, y, neg);
     return CHECK_INF && o == 0;
+  } else {
+    if (loc & LOC_ORIG) {
+      uint32_t w[2 * F::NW];
+      load_words<F>(w, points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
+      uint32_t o = 0;
+      if (CHECK_INF) {
+#pragma unroll
+        for (int i = 0; i < 2 * F::NW; i++) o |= w[i];
+      }
+      fe_unpack<F>(p.x, w);
+      Fe<F> y;
+      fe_unpack<F>(y, w + F::NW);
+      fe_cneg(p.y, y, loc >> 31);
+      return CHECK_INF && o == 0;
+    }
+    return slot_load_point<F, CHECK_INF>(p, slots + slot_offset<F>(loc));
   }
-  return slot_load_point<F, CHECK_INF>(p, slots + slot_offset<F>(loc));
 }
 // x coordinate only
 template <class F>
 __device__ __forceinline__ void load_operand_x(Fe<F>& x, uint32_t loc, const uint32_t* slots, const uint32_t* points) {
-  if (loc & LOC_ORIG) {
+  if constexpr (SlotFmt<F>::PACKED) {
+    int cs;
+    uint32_t neg;
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(operand_address<F>(loc, slots, points, cs, neg));
     uint32_t w[F::NW];
-    const u32x4* s4 = reinterpret_cast<const u32x4*>(points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
 #pragma unroll
     for (int i = 0; i < F::NW / 4; i++) {
-      const u32x4 v = s4[i];
+      const u32x4 v = s4[i * cs];
       w[4 * i] = v.x;
       w[4 * i + 1] = v.y;
       w[4 * i + 2] = v.z;
@@ -514,7 +587,21 @@ __device__ __forceinline__ void load_operand_x(Fe<F>& x, uint32_t loc, const uin
     }
     fe_unpack<F>(x, w);
   } else {
-    slot_load_fe<F>(x, slots + slot_offset<F>(loc));
+    if (loc & LOC_ORIG) {
+      uint32_t w[F::NW];
+      const u32x4* s4 = reinterpret_cast<const u32x4*>(points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
+#pragma unroll
+      for (int i = 0; i < F::NW / 4; i++) {
+        const u32x4 v = s4[i];
+        w[4 * i] = v.x;
+        w[4 * i + 1] = v.y;
+        w[4 * i + 2] = v.z;
+        w[4 * i + 3] = v.w;
+      }
+      fe_unpack<F>(x, w);
+    } else {
+      slot_load_fe<F>(x, slots + slot_offset<F>(loc));
+    }
   }
 }
 
@@ -1062,25 +1149,20 @@ __global__ void __launch_bounds__(64, MSMZ_REDUCE_OCC) k_reduce_quad(uint32_t* r
 
 // k_reduce_quad with every lane replaced by a DPP quad running the 4-lane addition: 16 lanes per group of 4
 // elements, 4 x 4 dependent field products per level.  Used for the small upper levels (latency-bound).
+// One group: lanes (q, s) = (element 0..3, product slot 0..3) of a 16-lane row; rows/c of window k hold n_in entries.
 template <class P>
-__global__ void __launch_bounds__(64, 2) k_reduce_quad16(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
-                                                         const uint32_t* c_in, uint32_t n_in, uint32_t groups,
-                                                         uint32_t total) {
+__device__ __forceinline__ void reduce_group16(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+                                               const uint32_t* c_in, uint32_t n_in, uint32_t A, bool live, uint32_t q,
+                                               int s, int base_lane) {
   constexpr int XW = P::ACC_WORDS;
   using Acc = typename P::Acc;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t grp = t >> 4, q = (t >> 2) & 3;
-  const int s = (int)(t & 3);
-  const bool live = grp < total;
-  const uint32_t k = live ? grp / groups : 0, A = live ? grp - k * groups : 0;
   const uint32_t e = A * 4 + q;
-  const int lane = threadIdx.x & 63, base_lane = (lane & ~15) + s;
   Acc r, c, v, w, got;
   P::zero(r);
   P::zero(c);
   if (live && e < n_in) {
-    P::load(r, rows_in + ((size_t)k * n_in + e) * XW);
-    P::load(c, c_in + ((size_t)k * n_in + e) * XW);
+    P::load(r, rows_in + (size_t)e * XW);
+    P::load(c, c_in + (size_t)e * XW);
   }
   {
     const int src[4] = {1, 3, 3, 2};
@@ -1105,8 +1187,57 @@ __global__ void __launch_bounds__(64, 2) k_reduce_quad16(uint32_t* rows_out, uin
     quad_fetch<P>(got, r, base_lane + 4 * src[q]);
     P::add_x4(c, r, got, s);                // L0 4 row, L1 C' = cs + tri
   }
-  if (live && q == 0 && s == 0) P::store(rows_out + (size_t)grp * XW, c);
-  if (live && q == 1 && s == 0) P::store(c_out + (size_t)grp * XW, c);
+  if (live && q == 0 && s == 0) P::store(rows_out + (size_t)A * XW, c);
+  if (live && q == 1 && s == 0) P::store(c_out + (size_t)A * XW, c);
+}
+
+template <class P>
+__global__ void __launch_bounds__(64, 1) k_reduce_quad16(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+                                                         const uint32_t* c_in, uint32_t n_in, uint32_t groups,
+                                                         uint32_t total) {
+  constexpr int XW = P::ACC_WORDS;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t grp = t >> 4, q = (t >> 2) & 3;
+  const int s = (int)(t & 3);
+  const bool live = grp < total;
+  const uint32_t k = live ? grp / groups : 0, A = live ? grp - k * groups : 0;
+  const int lane = threadIdx.x & 63, base_lane = (lane & ~15) + s;
+  reduce_group16<P>(rows_out + (size_t)k * groups * XW, c_out + (size_t)k * groups * XW,
+                    rows_in + (size_t)k * n_in * XW, c_in + (size_t)k * n_in * XW, n_in, A, live, q, s, base_lane);
+}
+
+// The LAST levels in one launch: one workgroup per window walks n_in -> ceil(n_in/4) -> ... -> 1 with a barrier
+// between levels (each level is 4 x 4 dependent field products of latency, whatever its size: as separate launches
+// the four levels below 128 entries cost ~85 us each, together ~4 x 35 us).  The window's rows/c ping-pong between
+// (r0, c0) and (r1, c1), n_in entries apart per window; the final C (the window sum) is written to c_final[k].
+constexpr int REDUCE_TAIL_T = 256;   // one wave per SIMD: the 4-lane additions need ~370 VGPRs (at 256 they spill to scratch)
+constexpr uint32_t REDUCE_TAIL_N = 128;   // entries per window at which the tail kernel takes over
+template <class P>
+__global__ void __launch_bounds__(REDUCE_TAIL_T, 1) k_reduce_tail(uint32_t* r0, uint32_t* c0, uint32_t* r1, uint32_t* c1,
+                                                                  uint32_t* c_final, uint32_t n_in, uint32_t stride) {
+  constexpr int XW = P::ACC_WORDS;
+  const uint32_t k = blockIdx.x;
+  uint32_t* rin = r0 + (size_t)k * stride * XW;
+  uint32_t* cin = c0 + (size_t)k * stride * XW;
+  uint32_t* rout = r1 + (size_t)k * stride * XW;
+  uint32_t* cout = c1 + (size_t)k * stride * XW;
+  const uint32_t q = (threadIdx.x >> 2) & 3;
+  const int s = (int)(threadIdx.x & 3);
+  const int lane = threadIdx.x & 63, base_lane = (lane & ~15) + s;
+  uint32_t n = n_in;
+  while (n > 1) {
+    const uint32_t g2 = (n + 3) / 4;
+    for (uint32_t A0 = 0; A0 < g2; A0 += REDUCE_TAIL_T / 16) {
+      const uint32_t A = A0 + (threadIdx.x >> 4);
+      reduce_group16<P>(rout, cout, rin, cin, n, A, A < g2, q, s, base_lane);
+    }
+    __syncthreads();   // same workgroup = same CU: the level's stores are visible to the next level's loads
+    uint32_t* t1 = rin; rin = rout; rout = t1;
+    uint32_t* t2 = cin; cin = cout; cout = t2;
+    n = g2;
+  }
+  // copy the window sum (C of the last level; for n_in == 1 the input C)
+  for (uint32_t j = threadIdx.x; j < (uint32_t)XW; j += REDUCE_TAIL_T) c_final[(size_t)k * XW + j] = cin[j];
 }
 
 

@@ -37,7 +37,9 @@ struct SortGeom {
   uint32_t ncb;        // coarse bins per bucket set = L >> fb
 };
 
-// The (half-)scalars of one input scalar as little-endian words that are shifted down window by window.
+// The (half-)scalars of one input scalar as little-endian words.  Windows are sliced with a word index that is the
+// same for every lane (the window loop is wave-uniform), so a window costs two register moves out of a uniform
+// switch plus one funnel shift instead of shifting the whole scalar down.
 template <class Fr, bool GLV>
 struct DigitStream {
   static constexpr int HALVES = GLV ? 2 : 1;
@@ -72,12 +74,27 @@ struct DigitStream {
       for (int j = 0; j < WORDS; j++) w[h][j] = 0;
     neg = carry = 0;
   }
-  // next signed digit of half h (msm-batched-affine.ts:180-199): returns l in [0, L], sets `ng` to its sign
-  __device__ __forceinline__ uint32_t next(int h, int c, uint32_t L, uint32_t& ng) {
-    uint32_t l = (w[h][0] & ((1u << c) - 1u)) + ((carry >> h) & 1u);
-#pragma unroll
-    for (int j = 0; j < WORDS - 1; j++) w[h][j] = __builtin_amdgcn_alignbit(w[h][j + 1], w[h][j], (uint32_t)c);
-    w[h][WORDS - 1] >>= c;
+  // c bits at (wave-uniform) bit position pos of half h
+  __device__ __forceinline__ uint32_t bits(int h, int pos, int c) const {
+    const int wi = __builtin_amdgcn_readfirstlane(pos >> 5);
+    uint32_t lo = 0, hi = 0;
+    switch (wi) {   // uniform: one scalar branch
+      case 0: lo = w[h][0]; hi = w[h][1]; break;
+      case 1: lo = w[h][1]; hi = w[h][2]; break;
+      case 2: lo = w[h][2]; hi = w[h][3]; break;
+      case 3: lo = w[h][3]; hi = WORDS > 4 ? w[h][WORDS > 4 ? 4 : 0] : 0u; break;
+      case 4: if (WORDS > 4) { lo = w[h][WORDS > 4 ? 4 : 0]; hi = w[h][WORDS > 5 ? 5 : 0]; } break;
+      case 5: if (WORDS > 4) { lo = w[h][WORDS > 5 ? 5 : 0]; hi = w[h][WORDS > 6 ? 6 : 0]; } break;
+      case 6: if (WORDS > 4) { lo = w[h][WORDS > 6 ? 6 : 0]; hi = w[h][WORDS > 7 ? 7 : 0]; } break;
+      case 7: if (WORDS > 4) { lo = w[h][WORDS > 7 ? 7 : 0]; } break;
+      default: break;
+    }
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(pos & 31)) & ((1u << c) - 1u);
+  }
+  // signed digit of window k of half h (msm-batched-affine.ts:180-199): returns l in [0, L], sets `ng` to its sign.
+  // Windows must be visited in order 0, 1, 2, ... (the carry).
+  __device__ __forceinline__ uint32_t next(int h, int k, int c, uint32_t L, uint32_t& ng) {
+    uint32_t l = bits(h, k * c, c) + ((carry >> h) & 1u);
     uint32_t cy = 0;
     if (l > L) {
       l = 2 * L - l;
@@ -87,14 +104,19 @@ struct DigitStream {
     ng = (cy ^ (neg >> h)) & (l != 0 ? 1u : 0u);   // the half scalar's own sign flips every digit's sign
     return l;
   }
+  // does the scalar need more than K windows?  (a carry out of the last one, or bits beyond it)
+  __device__ __forceinline__ bool overflows(int K, int c) const {
+    uint32_t o = carry & ((1u << HALVES) - 1u);
+#pragma unroll
+    for (int h = 0; h < HALVES; h++)
+      for (int pos = K * c; pos < 32 * WORDS; pos += 16) o |= bits(h, pos, 16);
+    return o != 0;
+  }
 };
 
-// counter[key] += 1, returning the old value.  (Measured: matching equal keys across the wave with ballots so that one
-// lane per key issues the LDS atomic costs ~80 VALU instructions per wave instruction and made k_hist 2.2x and
-// k_coarse 1.5x SLOWER than plain per-lane LDS atomics, which cost ~24 LDS cycles per wave instruction here.)
-__device__ __forceinline__ uint32_t counter_add(uint32_t* counter, uint32_t key, bool active) {
-  return active ? atomicAdd(&counter[key], 1u) : 0u;
-}
+// (Measured: matching equal keys across the wave with ballots so that one lane per key issues the LDS atomic costs
+// ~80 VALU instructions per wave instruction and made k_hist 2.2x and k_coarse 1.5x SLOWER than plain per-lane LDS
+// atomics, which cost ~24 LDS cycles per wave instruction here.)
 
 // bucket set (window, or sub-window of the sparse top window) and coarse bin of a non-zero digit
 __device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_t l, uint32_t entry) {
@@ -108,46 +130,48 @@ __device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_
 // bound: the host then repeats the MSM with one more bit), |= 4 when a scalar is not below the group order
 // (scalarsFromBytes' precondition, checked here instead of in a serial host loop).
 template <class Fr, bool GLV>
-__global__ void __launch_bounds__(256) k_hist(uint32_t* counts, MsmMeta* meta, const uint32_t* scalars, SortGeom g,
-                                              uint32_t nbins) {
+__global__ void __launch_bounds__(256) k_hist(uint32_t* counts, uint16_t* tile_counts, MsmMeta* meta, const uint32_t* scalars,
+                                              SortGeom g, uint32_t nbins) {
   extern __shared__ uint32_t s_hist[];
   constexpr int HALVES = GLV ? 2 : 1;
-  constexpr int PER = 8;   // scalars per thread
+  constexpr int PER = COARSE_ITEMS / HALVES;   // scalars per thread: one workgroup = one tile of k_coarse
   const uint32_t L = 1u << (g.c - 1);
   for (uint32_t b = threadIdx.x; b < nbins; b += 256) s_hist[b] = 0;
   __syncthreads();
-  uint32_t overflow = 0;
-#pragma unroll 1
+  uint32_t bad = 0;
+  // all of the thread's scalars are requested before any is sliced (one memory latency, not PER)
+  DigitStream<Fr, GLV> ds[PER];
+  uint32_t idx[PER];
+#pragma unroll
   for (int it = 0; it < PER; it++) {
-    const uint32_t i = (blockIdx.x * PER + it) * 256 + threadIdx.x;
-    const bool live = i < g.n;
-    DigitStream<Fr, GLV> ds;
-    if (live) {
-      if (!ds.load(scalars, i)) overflow |= 0x80000000u;
+    idx[it] = (blockIdx.x * PER + it) * 256 + threadIdx.x;
+    if (idx[it] < g.n) {
+      if (!ds[it].load(scalars, idx[it])) bad |= 4u;
     } else {
-      ds.clear();
+      ds[it].clear();
     }
+  }
 #pragma unroll 1
-    for (int k = 0; k < g.K; k++) {
+  for (int k = 0; k < g.K; k++) {
+#pragma unroll
+    for (int it = 0; it < PER; it++) {
 #pragma unroll
       for (int h = 0; h < HALVES; h++) {
         uint32_t ng;
-        const uint32_t l = ds.next(h, g.c, L, ng);
-        const uint32_t bin = l != 0 ? coarse_bin(g, k, l, (uint32_t)h * g.n + i) : 0u;
-        (void)counter_add(s_hist, bin, l != 0);
+        const uint32_t l = ds[it].next(h, k, g.c, L, ng);
+        if (l != 0) atomicAdd(&s_hist[coarse_bin(g, k, l, (uint32_t)h * g.n + idx[it])], 1u);
       }
     }
-    overflow |= ds.carry & 3u;
-#pragma unroll
-    for (int h = 0; h < HALVES; h++)
-#pragma unroll
-      for (int j = 0; j < DigitStream<Fr, GLV>::WORDS; j++) overflow |= ds.w[h][j] != 0 ? 1u : 0u;   // bits beyond the last window
   }
-  if (overflow & 0x80000000u) atomicOr(&meta->error, 4u);
-  if (overflow & 0x7fffffffu) atomicOr(&meta->error, 2u);
+#pragma unroll
+  for (int it = 0; it < PER; it++)
+    if (ds[it].overflows(g.K, g.c)) bad |= 2u;
+  if (bad) atomicOr(&meta->error, bad);
   __syncthreads();
+  uint16_t* row = tile_counts + (size_t)blockIdx.x * nbins;
   for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
     const uint32_t v = s_hist[b];
+    row[b] = (uint16_t)v;             // <= COARSE_TILE entries of a tile fall into one bin
     if (v) atomicAdd(&counts[b], v);
   }
 }
@@ -194,27 +218,28 @@ static __global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* base, const 
 }
 
 // ------------------------------------------------------------------------------------------------ coarse scatter
-// One tile = COARSE_TILE half-scalars (2048 scalars, or 1024 scalars with GLV).
-//   phase A  all K windows are sliced once just to count the tile's entries per bin (LDS atomics); then
-//            every bin's run is reserved in global memory with one atomic per bin -- all of them in flight together,
-//            ONE global-atomic latency per workgroup instead of one per window -- and a block scan turns the counts
-//            into staging offsets;
-//   phase B  window by window: slice again, rank the entries per bin (LDS atomics), stage them in LDS in bin
-//            order, write every bin's entries as one contiguous run.  Double-buffered staging: 2 barriers per window.
+// One tile = COARSE_TILE half-scalars (2048 scalars, or 1024 scalars with GLV) = the tile k_hist counted.
+//   setup    the tile's per-bin entry counts come from k_hist (2 bytes per bin); every bin's run is reserved in global
+//            memory with one atomic per bin -- all of them in flight together, ONE global-atomic latency per
+//            workgroup instead of one per window -- and a block scan turns the counts into staging offsets;
+//   windows  one by one: slice, rank the entries per bin (LDS atomics), stage them in LDS in bin order, write every
+//            bin's entries as one contiguous run.  Double-buffered staging: 2 barriers per window.
 // Algorithmic HBM bytes: 32 B read per scalar + 4 B written per entry.  Dynamic LDS: 3 * nbins words.
 template <class Fr, bool GLV>
 __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint32_t* bin_cursor, const uint32_t* bin_base,
-                                                     const uint32_t* scalars, SortGeom g, uint32_t nbins) {
+                                                     const uint16_t* tile_counts, const uint32_t* scalars, SortGeom g,
+                                                     uint32_t nbins) {
   constexpr int HALVES = GLV ? 2 : 1;
   constexpr int SC = COARSE_ITEMS / HALVES;           // scalars per thread
   extern __shared__ uint32_t s_dyn[];
-  uint32_t* s_off = s_dyn;                  // [nbins] counts, then offsets inside the window's staging order
-  uint32_t* s_cur = s_dyn + nbins;          // [nbins] running rank counters of phase B
+  uint32_t* s_off = s_dyn;                  // [nbins] counts, then offsets inside the tile's staging order
+  uint32_t* s_cur = s_dyn + nbins;          // [nbins] running rank counters
   uint32_t* s_gbase = s_dyn + 2 * nbins;    // [nbins] global address of this tile's run in each bin
-  __shared__ uint32_t s_stage[2][COARSE_TILE];
+  __shared__ uint32_t s_stage[2][COARSE_TILE];   // staged words, in bin order
+  __shared__ uint32_t s_dst[2][COARSE_TILE];     // ... and where each one goes in packed_out
   __shared__ uint32_t s_wave[COARSE_T / 64];
+  __shared__ uint32_t s_total;
   const uint32_t L = 1u << (g.c - 1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t fmask = (1u << g.fb) - 1u;
 
   DigitStream<Fr, GLV> ds[SC];
@@ -224,43 +249,17 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
     idx[s] = (blockIdx.x * SC + s) * COARSE_T + threadIdx.x;
     if (idx[s] < g.n) ds[s].load(scalars, idx[s]); else ds[s].clear();
   }
-  for (uint32_t b = threadIdx.x; b < nbins; b += COARSE_T) {
-    s_off[b] = 0;
-    s_cur[b] = 0;
-  }
-  __syncthreads();
-  // ---------------- phase A: counts of all windows
+  // reserve the runs (all bins at once), scan the counts
   {
-    DigitStream<Fr, GLV> dc[SC];
-#pragma unroll
-    for (int s = 0; s < SC; s++) dc[s] = ds[s];
-#pragma unroll 1
-    for (int k = 0; k < g.K; k++) {
-      const bool top = k == g.K - 1;
-      const uint32_t smask = top ? (1u << g.spread) - 1u : 0u;
-#pragma unroll
-      for (int s = 0; s < SC; s++) {
-#pragma unroll
-        for (int h = 0; h < HALVES; h++) {
-          uint32_t ng;
-          const uint32_t l = dc[s].next(h, g.c, L, ng);
-          const uint32_t entry = (uint32_t)h * g.n + idx[s];
-          const uint32_t bin = l != 0 ? (entry & smask) * g.ncb + ((l - 1) >> g.fb) : 0u;
-          (void)counter_add(s_off + (uint32_t)k * g.ncb, bin, l != 0);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // reserve the runs (all bins at once), scan the counts: offset of a bin inside ITS window's staging order
-  {
+    const uint16_t* row = tile_counts + (size_t)blockIdx.x * nbins;
     const uint32_t per = (nbins + COARSE_T - 1) / COARSE_T;   // consecutive bins per thread
     const uint32_t b0 = threadIdx.x * per;
     uint32_t sum = 0;
     for (uint32_t q = 0; q < per; q++) {
       const uint32_t b = b0 + q;
       if (b < nbins) {
-        const uint32_t cnt = s_off[b];
+        const uint32_t cnt = row[b];
+        s_cur[b] = 0;
         s_gbase[b] = cnt ? bin_base[b] + atomicAdd(&bin_cursor[b], cnt) : 0u;
         sum += cnt;
       }
@@ -270,14 +269,13 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
     for (uint32_t q = 0; q < per; q++) {
       const uint32_t b = b0 + q;
       if (b < nbins) {
-        const uint32_t cnt = s_off[b];
-        s_off[b] = ex;          // still relative to the tile's first entry: the window start is subtracted below
-        ex += cnt;
+        s_off[b] = ex;          // relative to the tile's first entry: the window start is subtracted below
+        ex += row[b];
       }
     }
+    if (threadIdx.x == 0) s_total = total;
   }
   __syncthreads();
-  // ---------------- phase B: window by window
 #pragma unroll 1
   for (int k = 0; k < g.K; k++) {
     const int buf = k & 1;
@@ -285,30 +283,38 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
     const uint32_t smask = top ? (1u << g.spread) - 1u : 0u;
     const uint32_t ncbk = top ? g.ncb << g.spread : g.ncb;   // bins of this window (its sub-windows follow each other)
     const uint32_t* off_k = s_off + (uint32_t)k * g.ncb;
+    uint32_t* cur_k = s_cur + (uint32_t)k * g.ncb;
     const uint32_t wbase = off_k[0];
 #pragma unroll
     for (int s = 0; s < SC; s++) {
 #pragma unroll
       for (int h = 0; h < HALVES; h++) {
         uint32_t ng;
-        const uint32_t l = ds[s].next(h, g.c, L, ng);
-        const uint32_t entry = (uint32_t)h * g.n + idx[s];
-        const uint32_t bi = l - 1;
-        const uint32_t bin = l != 0 ? (entry & smask) * g.ncb + (bi >> g.fb) : 0u;
-        const uint32_t rank = counter_add(s_cur + (uint32_t)k * g.ncb, bin, l != 0);
-        if (l != 0)
-          s_stage[buf][off_k[bin] - wbase + rank] = ((bi & fmask) << (g.idx_bits + 1)) | (ng << g.idx_bits) | entry;
+        const uint32_t l = ds[s].next(h, k, g.c, L, ng);
+#ifdef MSMZ_EXP_COARSE_NORANK
+        if (l == 0xffffffffu) {
+#else
+        if (l != 0) {
+#endif
+          const uint32_t entry = (uint32_t)h * g.n + idx[s];
+          const uint32_t bi = l - 1;
+          const uint32_t bin = (entry & smask) * g.ncb + (bi >> g.fb);
+          const uint32_t rank = atomicAdd(&cur_k[bin], 1u);
+          const uint32_t pos = off_k[bin] - wbase + rank;
+          s_stage[buf][pos] = ((bi & fmask) << (g.idx_bits + 1)) | (ng << g.idx_bits) | entry;
+          s_dst[buf][pos] = s_gbase[(uint32_t)k * g.ncb + bin] + rank;
+        }
       }
     }
     __syncthreads();
-    // one wave per bin: each run is a contiguous, coalesced store.  The next window stages into the other buffer;
-    // the barrier of the window after that orders this buffer's reuse behind these reads.
-    for (uint32_t b = wave; b < ncbk; b += COARSE_T / 64) {
-      const uint32_t gb = (uint32_t)k * g.ncb + b;
-      const uint32_t r0 = s_off[gb] - wbase, r1 = r0 + s_cur[gb];   // s_cur[gb] = the bin's entry count by now
-      const uint32_t gaddr = s_gbase[gb];
-      for (uint32_t p = r0 + lane; p < r1; p += 64) packed_out[gaddr + (p - r0)] = s_stage[buf][p];
-    }
+    // all threads copy the staged window out: consecutive staged words of a bin go to consecutive addresses, so every
+    // run is a contiguous, coalesced store.  The next window stages into the other buffer; the barrier of the window
+    // after that orders this buffer's reuse behind these reads.
+    const uint32_t wend = (uint32_t)k * g.ncb + ncbk < nbins ? off_k[ncbk] : s_total;
+#ifdef MSMZ_EXP_COARSE_NOWRITE
+    if (g.n == 0xffffffffu)
+#endif
+    for (uint32_t p = threadIdx.x; p < wend - wbase; p += COARSE_T) packed_out[s_dst[buf][p]] = s_stage[buf][p];
   }
 }
 
