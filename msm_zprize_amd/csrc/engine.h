@@ -11,11 +11,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/msmz.h"
 #include "kernels.h"
 #include "gen_kernels.h"
+#include "test_kernels.h"
 #include "host64.h"
 #include "multi.h"
 
@@ -385,6 +387,143 @@ class Engine : public IEngine {
     total->scatter_launches += part.scatter_launches;
     if (part.max_bucket > total->max_bucket) total->max_bucket = part.max_bucket;
     if (part.rounds > total->rounds) total->rounds = part.rounds;
+  }
+
+  // ------------------------------------------------------------------------------------------ stage-level test hooks
+  // (include/msmz_test.h: one device routine at a time, raw outputs)
+  int test_buffers(size_t in_bytes, size_t out_bytes, uint8_t** d_in, uint8_t** d_out) {
+    int st = stage_.ensure(in_bytes + out_bytes + 256);
+    if (st) return st;
+    *d_in = stage_.as<uint8_t>();
+    *d_out = stage_.as<uint8_t>() + ((in_bytes + 255) & ~(size_t)255);
+    return MSMZ_OK;
+  }
+
+  int test_field(int op, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) override {
+    if (!a || !b || !out || n == 0 || n > (1u << 22)) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    const size_t eb = (size_t)FE_BYTES * n;
+    uint8_t *d_in, *d_out;
+    int st = test_buffers(2 * eb, eb, &d_in, &d_out);
+    if (st) return st;
+    if ((st = slots_.ensure(((size_t)n + 64) * SlotFmt<F>::WORDS * 4))) return st;
+    MSMZ_HIP(hipMemcpyAsync(d_in, a, eb, hipMemcpyHostToDevice, stream_));
+    MSMZ_HIP(hipMemcpyAsync(d_in + eb, b, eb, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL((k_test_field<F>), dim3((n + 63) / 64), dim3(64), 0, stream_, (uint32_t*)d_out,
+                       (const uint32_t*)d_in, (const uint32_t*)(d_in + eb), (uint32_t)n, op, slots_.as<uint32_t>());
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipMemcpyAsync(out, d_out, eb, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    return MSMZ_OK;
+  }
+
+  int test_glv(const uint8_t* s, uint64_t n, uint8_t* s0, uint8_t* s1, uint8_t* neg) override {
+    if (!Fr::HAS_GLV) return MSMZ_ERR_UNSUPPORTED;
+    if (!s || !s0 || !s1 || !neg || n == 0 || n > (1u << 22)) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    uint8_t *d_in, *d_out;
+    int st = test_buffers(32 * n, 34 * n, &d_in, &d_out);
+    if (st) return st;
+    MSMZ_HIP(hipMemcpyAsync(d_in, s, 32 * n, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL((k_test_glv<Fr>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)d_out,
+                       (uint32_t*)(d_out + 16 * n), d_out + 32 * n, (const uint32_t*)d_in, (uint32_t)n);
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipMemcpyAsync(s0, d_out, 16 * n, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipMemcpyAsync(s1, d_out + 16 * n, 16 * n, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipMemcpyAsync(neg, d_out + 32 * n, 2 * n, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    return MSMZ_OK;
+  }
+
+  int test_digits(const uint8_t* s, uint64_t n, int c, int K, int glv, uint32_t* digits) override {
+    if (!s || !digits || n == 0 || n > (1u << 22) || c < 2 || c > 24 || K < 1 || K > kMaxWindows) return MSMZ_ERR_ARG;
+    if (glv && !Fr::HAS_GLV) return MSMZ_ERR_UNSUPPORTED;
+    MSMZ_HIP(hipSetDevice(device_));
+    const size_t ob = (size_t)(glv ? 2 : 1) * n * K * 4;
+    uint8_t *d_in, *d_out;
+    int st = test_buffers(32 * n, ob, &d_in, &d_out);
+    if (st) return st;
+    MSMZ_HIP(hipMemcpyAsync(d_in, s, 32 * n, hipMemcpyHostToDevice, stream_));
+    if (glv) {
+      if constexpr (Fr::HAS_GLV)
+        hipLaunchKernelGGL((k_test_digits<Fr, true>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)d_out,
+                           (const uint32_t*)d_in, (uint32_t)n, c, K);
+    } else {
+      hipLaunchKernelGGL((k_test_digits<Fr, false>), dim3((n + 255) / 256), dim3(256), 0, stream_, (uint32_t*)d_out,
+                         (const uint32_t*)d_in, (uint32_t)n, c, K);
+    }
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipMemcpyAsync(digits, d_out, ob, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    return MSMZ_OK;
+  }
+
+  int test_sort(const uint8_t* s, uint64_t n, int c, int glv, int force_fallback, uint32_t* geom, uint32_t* off,
+                uint64_t off_cap, uint32_t* refs, uint64_t refs_cap) override {
+    if (!s || !geom || n == 0 || n > (1u << 22)) return MSMZ_ERR_ARG;
+    if (glv && !Fr::HAS_GLV) return MSMZ_ERR_UNSUPPORTED;
+    MSMZ_HIP(hipSetDevice(device_));
+    msmz_opts opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.c = c;
+    Plan pl;
+    int st = make_plan(pl, n, glv != 0, opt, (uint32_t)n, !TE);
+    if (st) return st;
+    void* d_scalars = nullptr;
+    MSMZ_HIP(hipMalloc(&d_scalars, 32 * n));
+    MSMZ_HIP(hipMemcpyAsync(d_scalars, s, 32 * n, hipMemcpyHostToDevice, stream_));
+    const bool saved = force_atomic_sort_;
+    force_atomic_sort_ = saved || force_fallback != 0;
+    st = sort_phase(pl, (const uint32_t*)d_scalars);
+    force_atomic_sort_ = saved;
+    if (!st) st = fetch_meta(pl);
+    if (!st && (h_meta_->error & 4u)) st = MSMZ_ERR_RANGE;
+    if (!st) {
+      const uint32_t g8[8] = {(uint32_t)pl.c, (uint32_t)pl.K, (uint32_t)pl.Keff, pl.L, pl.nb, pl.n_entries, pl.max_bucket,
+                              (uint32_t)pl.spread};
+      memcpy(geom, g8, sizeof(g8));
+      if (off) {
+        if (off_cap < (uint64_t)pl.nb + 1) st = MSMZ_ERR_ARG;
+        else if (hipMemcpy(off, off_.p, ((size_t)pl.nb + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) st = MSMZ_ERR_HIP;
+      }
+      if (!st && refs) {
+        if (refs_cap < pl.n_entries) st = MSMZ_ERR_ARG;
+        else if (pl.n_entries && hipMemcpy(refs, refs_.p, (size_t)pl.n_entries * 4, hipMemcpyDeviceToHost) != hipSuccess)
+          st = MSMZ_ERR_HIP;
+      }
+    }
+    (void)hipFree(d_scalars);
+    return st;
+  }
+
+  int test_point(int op, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b, const uint8_t* b_inf, uint64_t n,
+                 uint8_t* out) override {
+    if (!a || !b || !out || n == 0 || n > (1u << 20)) return MSMZ_ERR_ARG;
+    MSMZ_HIP(hipSetDevice(device_));
+    const size_t pb = (size_t)2 * FE_BYTES * n;
+    uint8_t *d_in, *d_out;
+    int st = test_buffers(2 * pb + 2 * n, pb, &d_in, &d_out);
+    if (st) return st;
+    MSMZ_HIP(hipMemcpyAsync(d_in, a, pb, hipMemcpyHostToDevice, stream_));
+    MSMZ_HIP(hipMemcpyAsync(d_in + pb, b, pb, hipMemcpyHostToDevice, stream_));
+    uint8_t* d_ai = nullptr;
+    uint8_t* d_bi = nullptr;
+    if (a_inf) {
+      d_ai = d_in + 2 * pb;
+      MSMZ_HIP(hipMemcpyAsync(d_ai, a_inf, n, hipMemcpyHostToDevice, stream_));
+    }
+    if (b_inf) {
+      d_bi = d_in + 2 * pb + n;
+      MSMZ_HIP(hipMemcpyAsync(d_bi, b_inf, n, hipMemcpyHostToDevice, stream_));
+    }
+    using P = typename std::conditional<TE, TePolicy<F>, WeierPolicy<F>>::type;
+    const uint64_t threads = op == TP_ADD_X4 ? 4 * n : n;
+    hipLaunchKernelGGL((k_test_point<P, TE>), dim3((threads + 63) / 64), dim3(64), 0, stream_, (uint32_t*)d_out,
+                       (const uint32_t*)d_in, (const uint32_t*)(d_in + pb), d_ai, d_bi, (uint32_t)n, op);
+    MSMZ_HIP(hipGetLastError());
+    MSMZ_HIP(hipMemcpyAsync(out, d_out, pb, hipMemcpyDeviceToHost, stream_));
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    return MSMZ_OK;
   }
 
   // ------------------------------------------------------------------------------------------ shared phases

@@ -4,6 +4,7 @@
 #pragma once
 #include "gen_kernels.h"
 #include "kernels.h"
+#include "test_kernels.h"
 
 // curve ids as in include/msmz.h
 #if !defined(MSMZ_CURVE) || MSMZ_CURVE == 0
@@ -64,6 +65,13 @@
 
 #define MSMZ_INST_REDUCE_TE(F, Fr, PFX) MSMZ_INST_POLICY(TePolicy<F>, PFX)
 
+#define MSMZ_INST_TEST(F, Fr, P, TE, PFX)                                                                         \
+  PFX template __global__ void k_test_field<F>(uint32_t*, const uint32_t*, const uint32_t*, uint32_t, int, uint32_t*); \
+  PFX template __global__ void k_test_glv<Fr>(uint32_t*, uint32_t*, uint8_t*, const uint32_t*, uint32_t);         \
+  PFX template __global__ void k_test_digits<Fr, false>(uint32_t*, const uint32_t*, uint32_t, int, int);          \
+  PFX template __global__ void k_test_point<P, TE>(uint32_t*, const uint32_t*, const uint32_t*, const uint8_t*,   \
+                                                   const uint8_t*, uint32_t, int);
+
 #define MSMZ_INST_SCALAR(Fr, PFX)                                                                                 \
   PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, MsmMeta*, const uint32_t*, uint32_t, int, int, int); \
   PFX template __global__ void k_hist<Fr, false>(uint32_t*, uint16_t*, MsmMeta*, const uint32_t*, SortGeom, uint32_t);       \
@@ -77,11 +85,14 @@
   PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, MsmMeta*, const uint32_t*, uint32_t, int, int, int); \
   PFX template __global__ void k_hist<Fr, true>(uint32_t*, uint16_t*, MsmMeta*, const uint32_t*, SortGeom, uint32_t);        \
   PFX template __global__ void k_coarse<Fr, true>(uint32_t*, uint32_t*, const uint32_t*, const uint16_t*, const uint32_t*, SortGeom, uint32_t); \
+  PFX template __global__ void k_test_digits<Fr, true>(uint32_t*, const uint32_t*, uint32_t, int, int);           \
+  MSMZ_INST_TEST(F, Fr, WeierPolicy<F>, false, PFX)                                                               \
   MSMZ_INST_SCALAR(Fr, PFX)
 
 #define MSMZ_INST_MISC_TE(F, Fr, PFX)                                                              \
   PFX template __global__ void k_te_points_to_niels<F>(uint32_t*, const uint32_t*, uint32_t, uint32_t*); \
   PFX template __global__ void k_te_points_from_niels<F>(uint32_t*, const uint32_t*, uint32_t);    \
+  MSMZ_INST_TEST(F, Fr, TePolicy<F>, true, PFX)                                                    \
   MSMZ_INST_SCALAR(Fr, PFX)
 
 #define MSMZ_INST_GEN(F, Fr, PFX)                                                \

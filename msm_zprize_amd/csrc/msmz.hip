@@ -9,6 +9,7 @@ MSMZ_TE_FIELDS(X)
 #undef X
 }  // namespace msmz
 #include "engine.h"
+#include "../../include/msmz_test.h"
 
 namespace msmz {
 
@@ -168,6 +169,24 @@ int msmz_msm_resident(msmz_ctx* c, uint64_t ph, uint64_t sh, uint64_t n, const m
                       int* out_inf, msmz_log* log) {
   if (!c) return MSMZ_ERR_ARG;
   return c->engine->msm(ph, nullptr, sh, n, o, out, out_inf, log);
+}
+
+int msmz_test_field(msmz_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) {
+  return c ? c->engine->test_field(op, a, b, n, out) : MSMZ_ERR_ARG;
+}
+int msmz_test_glv(msmz_ctx* c, const uint8_t* s, uint64_t n, uint8_t* s0, uint8_t* s1, uint8_t* neg) {
+  return c ? c->engine->test_glv(s, n, s0, s1, neg) : MSMZ_ERR_ARG;
+}
+int msmz_test_digits(msmz_ctx* c, const uint8_t* s, uint64_t n, int cc, int K, int glv, uint32_t* digits) {
+  return c ? c->engine->test_digits(s, n, cc, K, glv, digits) : MSMZ_ERR_ARG;
+}
+int msmz_test_sort(msmz_ctx* c, const uint8_t* s, uint64_t n, int cc, int glv, int force_fallback, uint32_t* geom,
+                   uint32_t* off, uint64_t off_cap, uint32_t* refs, uint64_t refs_cap) {
+  return c ? c->engine->test_sort(s, n, cc, glv, force_fallback, geom, off, off_cap, refs, refs_cap) : MSMZ_ERR_ARG;
+}
+int msmz_test_point(msmz_ctx* c, int op, const uint8_t* a, const uint8_t* ai, const uint8_t* b, const uint8_t* bi,
+                    uint64_t n, uint8_t* out) {
+  return c ? c->engine->test_point(op, a, ai, b, bi, n, out) : MSMZ_ERR_ARG;
 }
 
 int msmz_point_add(int curve_id, const uint8_t* a, int ai, const uint8_t* b, int bi, uint8_t* out, int* oi) {

@@ -43,6 +43,16 @@ class IEngine {
   virtual int free_handle(uint64_t h) = 0;
   virtual int msm(uint64_t ph, const uint8_t* host_scalars, uint64_t sh, uint64_t n, const msmz_opts* o, uint8_t* out,
                   int* out_inf, msmz_log* log) = 0;
+  // stage-level test hooks (include/msmz_test.h)
+  virtual int test_field(int, const uint8_t*, const uint8_t*, uint64_t, uint8_t*) { return MSMZ_ERR_UNSUPPORTED; }
+  virtual int test_glv(const uint8_t*, uint64_t, uint8_t*, uint8_t*, uint8_t*) { return MSMZ_ERR_UNSUPPORTED; }
+  virtual int test_digits(const uint8_t*, uint64_t, int, int, int, uint32_t*) { return MSMZ_ERR_UNSUPPORTED; }
+  virtual int test_sort(const uint8_t*, uint64_t, int, int, int, uint32_t*, uint32_t*, uint64_t, uint32_t*, uint64_t) {
+    return MSMZ_ERR_UNSUPPORTED;
+  }
+  virtual int test_point(int, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint64_t, uint8_t*) {
+    return MSMZ_ERR_UNSUPPORTED;
+  }
 };
 
 // entries of the first n that live on shard g of G
@@ -208,6 +218,24 @@ class MultiEngine : public IEngine {
       }
     }
     return MSMZ_OK;
+  }
+
+  int test_field(int op, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) override {
+    return workers_[0]->eng->test_field(op, a, b, n, out);
+  }
+  int test_glv(const uint8_t* s, uint64_t n, uint8_t* s0, uint8_t* s1, uint8_t* neg) override {
+    return workers_[0]->eng->test_glv(s, n, s0, s1, neg);
+  }
+  int test_digits(const uint8_t* s, uint64_t n, int c, int K, int glv, uint32_t* d) override {
+    return workers_[0]->eng->test_digits(s, n, c, K, glv, d);
+  }
+  int test_sort(const uint8_t* s, uint64_t n, int c, int glv, int fb, uint32_t* geom, uint32_t* off, uint64_t oc,
+                uint32_t* refs, uint64_t rc) override {
+    return workers_[0]->eng->test_sort(s, n, c, glv, fb, geom, off, oc, refs, rc);
+  }
+  int test_point(int op, const uint8_t* a, const uint8_t* ai, const uint8_t* b, const uint8_t* bi, uint64_t n,
+                 uint8_t* out) override {
+    return workers_[0]->eng->test_point(op, a, ai, b, bi, n, out);
   }
 
  private:
