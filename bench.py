@@ -108,33 +108,52 @@ def main():
     if rank == 0:
         st0 = stats[-1]
         K, c = st0.K, st0.c
-        M = n * (2 if args.glv else 1)
         ms_per_step = elapsed / args.steps * 1e3
-        # roofline of the HBM-bound kernel the north_star names: the bucket scatter.  Algorithmic bytes
-        # per launch = M*K*(4 B digit read + 4 B reference write); duration from HIP
-        # events recorded on the library's own stream around that kernel, averaged over the timed steps.
+        # Roofline of the HBM-bound kernel the north_star names, the bucket scatter k_coarse: it
+        # reads every scalar once (32 B) and writes one packed (bucket bits | sign | index) word per non-zero digit
+        # (4 B); digits are never materialized.  Algorithmic bytes per launch = 32 n + 4 E.  Duration: HIP events
+        # recorded on the library's own stream around that kernel, averaged over the timed steps.
+        entries = statistics.mean(float(s.n_entries) for s in stats)
         scatter_ms = statistics.mean(float(s.scatter_kernel_ms) for s in stats)
-        scatter_bytes = M * K * 8
+        scatter_bytes = 32 * n + 4 * entries
         achieved = scatter_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
+        # the whole sort (scalars -> sorted references + bucket offsets): same algorithmic bytes
+        # (the references are written once more, as the sort's output) over histogram + scan + coarse + fine
+        sort_ms = statistics.mean(float(s.stage_ms[0]) + float(s.stage_ms[1]) + float(s.stage_ms[2]) for s in stats)
         acc_ms = statistics.mean(float(s.stage_ms[4]) for s in stats)
         pairs = statistics.mean(float(s.n_pairs) for s in stats)
+        per_step = [float(s.stage_ms[7]) for s in stats]   # host wall clock of each msmz_msm_resident call
+        extra = extra_measurements(par, points, n, args) if world == 1 else {}
         result = {
             "metric": "Mpoint-adds/s (ms per MSM in ms_per_step)",
             "value": total_entries / elapsed / 1e6,
             "unit": "Mpoint-adds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_msm_median": statistics.median(per_step),
+            "ms_per_msm_stdev": statistics.stdev(per_step) if len(per_step) > 1 else 0.0,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (28-bit lazy Montgomery, i64 accumulate)", "data": "synthetic",
             "config": {"workload": f"BLS12-377 G1 MSM 2^{log2n} per GPU x {world} GPU, "
                                    f"{'GLV' if args.glv else 'no GLV'}, affine buckets (batched-affine), msmUnsafe",
                        "log2n_per_gpu": log2n, "c": c, "K": K, "glv": bool(args.glv),
                        "point_adds_per_msm": total_entries / args.steps / world, "sharding": f"input-split x{world}"},
-            "roofline": {"kernel": "k_scatter_coarse", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0,
+            "roofline": {"kernel": "k_coarse (bucket scatter: scalars -> per-bin runs of packed references)", "bound": "hbm",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          # PMC bytes were collected on the 2^20 no-GLV workload only
-                         "traffic": scatter_traffic() if (log2n == 20 and not args.glv) else None,
+                         "traffic": pmc_traffic("k_coarse") if (log2n == 20 and not args.glv) else None,
                          "bytes_per_launch": scatter_bytes, "avg_launch_ms": scatter_ms},
+            "sort_roofline": {"stage": "whole bucket sort: k_hist + k_bin_scan + k_coarse + k_fine", "bound": "hbm",
+                              "achieved": scatter_bytes / (sort_ms * 1e-3) / 1e9 if sort_ms > 0 else 0.0, "peak": 8000.0,
+                              "unit": "GB/s", "frac": scatter_bytes / (sort_ms * 1e-3) / 1e9 / 8000.0 if sort_ms > 0 else 0.0,
+                              "traffic": pmc_traffic("sort") if (log2n == 20 and not args.glv) else None,
+                              "bytes": scatter_bytes, "avg_ms": sort_ms},
+            "batch_add_roofline": {"kernel": "k_batch_add (all tree rounds)", "bound": "hbm (measured: memory-bound, DESIGN.md)",
+                                   "algorithmic_bytes_per_addition": 544,
+                                   "achieved": pairs * 544 / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0, "peak": 8000.0,
+                                   "unit": "GB/s", "frac": pairs * 544 / (acc_ms * 1e-3) / 1e9 / 8000.0 if acc_ms > 0 else 0.0,
+                                   "traffic": pmc_traffic("k_batch_add") if (log2n == 20 and not args.glv) else None,
+                                   "additions": pairs, "avg_ms": acc_ms},
             "valu_roofline": {"kernel": "k_batch_add (all rounds)", "bound": "int32 VALU (v_mad_i64_i32)",
                               "achieved": pairs * 6 / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
                               "peak": 72.0, "unit": "Gmodmul/s",
@@ -143,6 +162,7 @@ def main():
             "stage_ms": {name: statistics.mean(float(s.stage_ms[i]) for s in stats)
                          for i, name in enumerate(["digits", "scan", "scatter", "plan", "accumulate", "reduce", "final", "total"])},
         }
+        result.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(params, args.cpu_log2n)
         print(json.dumps(result), flush=True)
@@ -151,15 +171,56 @@ def main():
         dist.destroy_process_group()
 
 
-def scatter_traffic():
-    """HBM bytes per launch of k_scatter_coarse from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE and WRITE_SIZE, separate passes; see profiles/README.md for the corrections applied)."""
-    path = os.path.join(ROOT, "profiles", "r01_scatter_pmc.json")
+def pmc_traffic(key):
+    """HBM bytes per launch (k_coarse) / per MSM (sort, k_batch_add) from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH_SIZE and WRITE_SIZE, separate passes; see profiles/README.md for the corrections applied)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+            return json.load(f)[key]["hbm_bytes"]
     except Exception:
         return None
+
+
+def extra_measurements(par, points, n, args):
+    """Numbers SURVEY.md section 8(d) asks for beside the resident-scalar rate (never the bench `value`):
+    h2d_inclusive_ms  one MSM with the 32-byte scalars handed over as a HOST buffer (msmz_msm: H2D of the scalars +
+                      all kernels + D2H of the result) -- section 8(d)'s definition of the metric;
+    byte_route_ms     the ZPrize `compute_msm(points, scalars)` entry (scripts/zprize23/submission-bls377.ts:20-65):
+                      canonical little-endian point bytes are uploaded and converted on the device (pointsFromBytes),
+                      then the MSM runs with host scalars."""
+    import msm_zprize_amd as m
+    from msm_zprize_amd import _native
+    curve = par._c
+    opts = {"glv": args.glv, "c": args.c}
+    sc = par.randomScalars(n, 424242)
+    sbuf = ctypes.create_string_buffer(32 * n)
+    _native.check(_native.lib().msmz_download_scalars(curve._ctx, sc.handle, 0, n, sbuf), "download")
+    raw = sbuf.raw
+    times = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        par.msmUnsafe(raw, points, n, False, opts)
+        times.append((time.perf_counter() - t0) * 1e3)
+    out = {"h2d_inclusive_ms": statistics.median(times[1:])}
+    if n <= (1 << 22):
+        fb = curve.fe_bytes
+        pbuf = ctypes.create_string_buffer(2 * fb * n)
+        _native.check(_native.lib().msmz_download_points(curve._ctx, points.handle, 0, n, pbuf, None), "download")
+        praw = pbuf.raw
+        t_up, t_all = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            up = par.pointsFromBytes(praw, n)
+            t1 = time.perf_counter()
+            par.msmUnsafe(raw, up, n, False, opts)
+            t2 = time.perf_counter()
+            up.free()
+            t_up.append((t1 - t0) * 1e3)
+            t_all.append((t2 - t0) * 1e3)
+        out["byte_route_ms"] = {"upload_points": statistics.median(t_up), "upload_plus_msm": statistics.median(t_all)}
+    sc.free()
+    return out
 
 
 def effective_cpus():

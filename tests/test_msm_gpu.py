@@ -329,3 +329,18 @@ def test_debug_environment_cannot_change_a_result(monkeypatch):
     want = _oracle("bls12-377", curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
     assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"] == want
     curve.close()
+
+
+def test_window_sizes_that_take_the_fallback_sort(curves):
+    """a user-chosen window so large that its coarse bins do not fit the LDS-staged sort (c = 22: 2^21 buckets per
+    window, 1024 bins per window): the one-pass atomic sort + the same plan / rounds / reduction must give the same
+    result (the reference accepts any c: msm-batched-affine.ts:79-97)"""
+    curve = curves("bls12-377")
+    n = 3000
+    pts = curve.Parallel.randomPointsFast(n, 31337)
+    sc = curve.Parallel.randomScalars(n, 31338)
+    want = _oracle("bls12-377", curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
+    for glv, c in ((0, 22), (1, 22), (0, 19)):
+        assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": glv, "c": c})["result"] == want, (glv, c)
+    assert curve.Parallel.msmProjective(sc, pts, n, {"c": 22})["result"] == want
+    pts.free(); sc.free()

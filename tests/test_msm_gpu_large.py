@@ -108,6 +108,36 @@ def test_config5_shard_2e23_per_gpu(mod):
     curve.close()
 
 
+def test_inputs_beyond_one_sorting_pass(mod):
+    """sizes whose (half-)scalar count exceeds one sorting pass (2^24 entries) run as index ranges
+    inside the engine: BLS12-377 2^25 without GLV (two passes of 2^24) and 2^24 with GLV (two passes of 2^23 points,
+    each addressing its endomorphism images behind the WHOLE set) -- closed form as above"""
+    curve = mod.Weierstrass.create(mod.curves.bls12377Params)
+    n = 1 << 25
+    pts = curve.Parallel.randomPointsFast(n, 61)
+    sc = curve.Parallel.randomScalars(n, 62)
+    assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"] == _expected("bls12-377", 61, 62, n)
+    h = 1 << 24
+    assert curve.Parallel.msmUnsafe(sc, pts, h, False, {"glv": 1})["result"] == _expected("bls12-377", 61, 62, h)
+    pts.free(); sc.free()
+    curve.close()
+
+
+def test_two_engine_context_at_full_size(mod):
+    """msmz_create with n_devices = 2 (two engines on GPU 0): 2^20 points split in blocks over the engines, every
+    variant equal to the closed form"""
+    mod.startThreads(devices=[0, 0])
+    curve = mod.Weierstrass.create(mod.curves.bls12377Params)
+    mod.startThreads()
+    n = 1 << 20
+    pts = curve.Parallel.randomPointsFast(n, 11)
+    sc = curve.Parallel.randomScalars(n, 12)
+    want = _expected("bls12-377", 11, 12, n)
+    assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 0})["result"] == want
+    assert curve.Parallel.msmUnsafe(sc, pts, n, True, {"glv": 1})["result"] == want
+    curve.close()
+
+
 @pytest.mark.parametrize("label", ["bls12-377", "pallas", "ed-on-bls12-377"])
 def test_equal_scalars_one_long_bucket_per_window(mod, label):
     """Adversarial input: all 2^16 scalars equal, so every window has ONE bucket holding every point (the
