@@ -924,14 +924,16 @@ class Engine : public IEngine {
     const int ev_plan0 = pl.ei;
     mark(pl);
     const uint32_t n_chunks = (nb + PLAN_CHUNK - 1) / PLAN_CHUNK;
-    if ((st = rscan_.ensure((size_t)PLAN_RMAX * n_chunks * 4))) return st;
+    // chunk totals per round, then the per-workgroup scratch of the rounds beyond PLAN_RL
+    const size_t pair_words = (size_t)n_chunks * (PLAN_RMAX - PLAN_RL) * PLAN_T;
+    if ((st = rscan_.ensure(((size_t)PLAN_RMAX * n_chunks + pair_words) * 4))) return st;
     if ((st = desc_.ensure((size_t)pl.K * pl.M * 8))) return st;
     if ((st = bfin_.ensure((size_t)nb * 16))) return st;
     hipLaunchKernelGGL(k_plan_count, dim3(n_chunks), dim3(PLAN_T), 0, stream_, rscan_.as<uint32_t>(), off_.as<uint32_t>(),
                        nb, n_chunks, d_meta, tail_skip_);
     hipLaunchKernelGGL(k_plan_emit, dim3(n_chunks), dim3(PLAN_T), 0, stream_, desc_.as<uint2>(), bfin_.as<uint4>(),
                        d_meta, rscan_.as<uint32_t>(), off_.as<uint32_t>(), refs_.as<uint32_t>(), nb, n_chunks,
-                       tail_skip_);
+                       tail_skip_, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks);
     MSMZ_HIP(hipGetLastError());
     if ((st = fetch_meta(pl))) return st;      // the ONE host round trip before the final fetch
     if (h_meta_->error & 4u) return MSMZ_ERR_RANGE;

@@ -36,8 +36,18 @@
 // two moves per product (seen in k_batch_add's backward pass: 832 + 728 extra instructions per addition).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MSMZ_OPAQUE_LIMB(x) asm("" : "+v"(x))
+#define MSMZ_OPAQUE_ACC(x) asm("" : "+v"(x))
 #else
 #define MSMZ_OPAQUE_LIMB(x) (void)0
+#define MSMZ_OPAQUE_ACC(x) (void)0
+#endif
+// MSMZ_FE_ILP = 1 (set per translation unit): a column of fe_mul / fe_sqr is summed in THREE independent chains that
+// the compiler may not fuse back into one.  A back-to-back dependent v_mad_i64_i32 issues only every ~16 cycles, so a
+// kernel that runs one or two waves per SIMD (the bucket reduction: long dependent point additions, 256+ VGPRs) is
+// bound by that latency; kernels at four waves per SIMD (k_batch_add) hide it and keep the single chain, which has
+// ~70 fewer instructions per product.
+#ifndef MSMZ_FE_ILP
+#define MSMZ_FE_ILP 0
 #endif
 
 namespace msmz {
@@ -136,16 +146,27 @@ MSMZ_HD void fe_mul(Fe<F>& r, const Fe<F>& a_in, const Fe<F>& b_in) {
   for (int k = 0; k < 2 * N - 1; k++) {
     const int lo = k - (N - 1) > 0 ? k - (N - 1) : 0;
     const int hi = k < N - 1 ? k : N - 1;
-    // two independent accumulation chains per column (a*b terms / m*p terms): a kernel that runs one or two waves per
-    // SIMD (the reduction levels) is bound by the latency of back-to-back dependent v_mad_i64_i32
     int64_t accp = 0;
+#if MSMZ_FE_ILP
+    int64_t acce = 0;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      if ((i - lo) & 1) acce += (int64_t)a.l[i] * (int64_t)b.l[k - i]; else acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+    }
+#else
 #pragma unroll
     for (int i = lo; i <= hi; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+#endif
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       const int j = k - i;
       if (j >= 1 && F::PL[j] != 0) accp += (int64_t)m[i] * (int64_t)F::NPL[j];
     }
+#if MSMZ_FE_ILP
+    MSMZ_OPAQUE_ACC(acce);
+    MSMZ_OPAQUE_ACC(accp);
+    acc += acce;
+#endif
     acc += accp;
     if (k < N) {
       uint32_t q = (uint32_t)acc;
@@ -193,6 +214,10 @@ MSMZ_HD void fe_sqr(Fe<F>& r, const Fe<F>& a_in) {
       const int j = k - i;
       if (j >= 1 && F::PL[j] != 0) accp += (int64_t)m[i] * (int64_t)F::NPL[j];
     }
+#if MSMZ_FE_ILP
+    MSMZ_OPAQUE_ACC(off);
+    MSMZ_OPAQUE_ACC(accp);
+#endif
     acc += off * 2 + accp;
     if (k < N) {
       uint32_t q = (uint32_t)acc;

@@ -404,8 +404,9 @@ __device__ __forceinline__ uint32_t scan_value(const uint32_t* in, uint32_t g, u
   return (s + m - 1) >> (r + 1);
 }
 
+template <int T = 256>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* lds) {
-  // 256 threads: wave-level inclusive scan by shuffles, then across the 4 waves through LDS
+  // T threads: wave-level inclusive scan by shuffles, then across the T/64 waves through LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t x = v;
 #pragma unroll
@@ -417,7 +418,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < SCAN_T / 64; w++) {
+  for (int w = 0; w < T / 64; w++) {
     uint32_t t = lds[w];
     if (w < wave) base += t;
     tot += t;

@@ -22,8 +22,8 @@
 
 namespace msmz {
 
-constexpr int PLAN_T = 256;
-constexpr int PLAN_PER = 4;                       // consecutive buckets per thread (counting / scan phases)
+constexpr int PLAN_T = 512;
+constexpr int PLAN_PER = 2;                       // consecutive buckets per thread (counting / scan phases)
 constexpr int PLAN_CHUNK = PLAN_T * PLAN_PER;     // buckets per workgroup
 constexpr int PLAN_RMAX = 26;                     // rounds supported (bucket sizes < 2^26)
 constexpr int PLAN_RL = 8;                        // rounds whose per-bucket pair numbers sit in LDS (one thread per PAIR);
@@ -70,15 +70,25 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_count(uint32_t* chunk_pa
 static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4* bfin, MsmMeta* meta,
                                                              const uint32_t* chunk_pairs, const uint32_t* off,
                                                              const uint32_t* refs, uint32_t nb, uint32_t n_chunks,
-                                                             int tail_skip) {
+                                                             int tail_skip, uint32_t* pair_scratch) {
   __shared__ uint32_t s_before[PLAN_RMAX];              // pairs of round r in the chunks before this one
   __shared__ uint32_t s_total[PLAN_RMAX];               // pairs of round r
   __shared__ uint32_t s_rbase[PLAN_RMAX + 1];           // first record of round r's result array
   __shared__ uint32_t s_start[PLAN_CHUNK + 1];          // bucket offsets of the chunk
   __shared__ uint32_t s_pref[PLAN_RL][PLAN_CHUNK + 1];  // r < PLAN_RL: pairs of round r in the chunk's buckets before b
-  __shared__ uint32_t s_pair[PLAN_RMAX - PLAN_RL][PLAN_T];   // r >= PLAN_RL: running pair number of the thread's bucket
+  // r >= PLAN_RL: running pair number of the thread's current bucket -- rarely needed (buckets > 256 entries), so it
+  // lives in a per-workgroup slice of global scratch instead of 36 KB of LDS (which would cost occupancy)
+  uint32_t* s_pair = pair_scratch + (size_t)blockIdx.x * (PLAN_RMAX - PLAN_RL) * PLAN_T;
   __shared__ uint32_t s_wave[PLAN_T / 64];
   __shared__ uint16_t s_owner[PLAN_TILE];              // chunk bucket of every pair of the current tile
+#ifdef MSMZ_EXP_STAMPS
+  uint64_t ts[12];
+  int nts = 0;
+#define MSMZ_PSTAMP() ts[nts++] = __builtin_amdgcn_s_memtime()
+#else
+#define MSMZ_PSTAMP() (void)0
+#endif
+  MSMZ_PSTAMP();
   const int R = plan_rounds(meta->max_bucket, tail_skip);
   const int RL = R < PLAN_RL ? R : PLAN_RL;
   if (threadIdx.x < PLAN_RMAX) {
@@ -107,6 +117,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     }
   }
   __syncthreads();
+  MSMZ_PSTAMP();   // 1: chunk totals
   if (threadIdx.x == 0) {
     uint32_t base = 0;
     for (int r = 0; r < PLAN_RMAX; r++) {
@@ -123,7 +134,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
       }
     }
   }
-  // per round: exclusive scan of the buckets' pair counts (thread t owns buckets 4t .. 4t+3)
+  // per round: exclusive scan of the buckets' pair counts (thread t owns PLAN_PER consecutive buckets)
   const uint32_t b0 = threadIdx.x * PLAN_PER;
   uint32_t size[PLAN_PER];
 #pragma unroll
@@ -133,7 +144,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
 #pragma unroll
     for (int q = 0; q < PLAN_PER; q++) s += pairs_in_round(size[q], r);
     uint32_t total;
-    uint32_t ex = block_exclusive_scan(s, &total, s_wave);
+    uint32_t ex = block_exclusive_scan<PLAN_T>(s, &total, s_wave);
     if (r < PLAN_RL) {
 #pragma unroll
       for (int q = 0; q < PLAN_PER; q++) {
@@ -142,10 +153,11 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
       }
       if (threadIdx.x == PLAN_T - 1) s_pref[r][PLAN_CHUNK] = ex;
     } else {
-      s_pair[r - PLAN_RL][threadIdx.x] = ex;
+      s_pair[(r - PLAN_RL) * PLAN_T + threadIdx.x] = ex;
     }
   }
   __syncthreads();
+  MSMZ_PSTAMP();   // 2: per-round scans
   // location of the element at relative position `pos` of chunk bucket b before round r (see the header); prr = this
   // thread's running pair numbers for the rounds >= PLAN_RL (only meaningful on the bucket-by-bucket path)
   auto location = [&](uint32_t b, uint32_t st, uint32_t sz, uint32_t pos, int r) -> uint32_t {
@@ -156,7 +168,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     }
     int rr = 31 - __builtin_clz(rem - 1);
     if (rr > r - 1) rr = r - 1;
-    const uint32_t pr = rr < PLAN_RL ? s_pref[rr][b] : s_pair[rr - PLAN_RL][threadIdx.x];
+    const uint32_t pr = rr < PLAN_RL ? s_pref[rr][b] : s_pair[(rr - PLAN_RL) * PLAN_T + threadIdx.x];
     return s_rbase[rr] + s_before[rr] + pr + (pos >> (rr + 1));
   };
   // rounds < PLAN_RL: one thread per pair, descriptors written in pair order (coalesced).  The pair -> bucket map
@@ -176,7 +188,8 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
         for (uint32_t t = lo; t < hi; t++) s_owner[t - tile0] = (uint16_t)b;
       }
       __syncthreads();
-      for (uint32_t t = tile0 + threadIdx.x; t < tile1; t += PLAN_T) {
+#pragma unroll 4
+      for (uint32_t t = tile0 + threadIdx.x; t < tile1; t += PLAN_T) {   // unrolled: four pairs' reference loads in flight
         const uint32_t b = s_owner[t - tile0];
         const uint32_t st = s_start[b], sz = s_start[b + 1] - st;
         const uint32_t a = (t - s_pref[r][b]) << (r + 1);
@@ -185,6 +198,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
       __syncthreads();
     }
   }
+  MSMZ_PSTAMP();   // 3: descriptors of rounds < RL
   // rounds >= PLAN_RL (very long buckets) and the per-bucket records: bucket by bucket
 #pragma unroll 1
   for (int q = 0; q < PLAN_PER; q++) {
@@ -194,7 +208,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     for (int r = PLAN_RL; r < R; r++) {
       const uint32_t np = pairs_in_round(sz, r);
       if (np == 0) break;
-      uint2* d = desc + s_rbase[r] + s_before[r] + s_pair[r - PLAN_RL][threadIdx.x];
+      uint2* d = desc + s_rbase[r] + s_before[r] + s_pair[(r - PLAN_RL) * PLAN_T + threadIdx.x];
       for (uint32_t j = 0; j < np; j++) {
         const uint32_t a = j << (r + 1);
         d[j] = make_uint2(location(b, st, sz, a, r), location(b, st, sz, a + (1u << r), r));
@@ -207,8 +221,17 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     if (sz > (2u << R)) fin.z = location(b, st, sz, 2u << R, R);
     if (sz > (3u << R)) fin.w = location(b, st, sz, 3u << R, R);
     bfin[g0 + b] = fin;
-    for (int r = PLAN_RL; r < R; r++) s_pair[r - PLAN_RL][threadIdx.x] += pairs_in_round(sz, r);   // -> next bucket
+    for (int r = PLAN_RL; r < R; r++) s_pair[(r - PLAN_RL) * PLAN_T + threadIdx.x] += pairs_in_round(sz, r);   // -> next bucket
   }
+#ifdef MSMZ_EXP_STAMPS
+  MSMZ_PSTAMP();   // 4: bfin
+  asm volatile("s_waitcnt vmcnt(0)");
+  MSMZ_PSTAMP();
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
+    printf("k_plan_emit chunk %u: totals %llu  scans %llu  desc %llu  bfin %llu  drain %llu (cycles) R=%d np0=%u\n", blockIdx.x,
+           (unsigned long long)(ts[1] - ts[0]), (unsigned long long)(ts[2] - ts[1]), (unsigned long long)(ts[3] - ts[2]),
+           (unsigned long long)(ts[4] - ts[3]), (unsigned long long)(ts[5] - ts[4]), R, s_pref[0][PLAN_CHUNK]);
+#endif
 }
 
 }  // namespace msmz

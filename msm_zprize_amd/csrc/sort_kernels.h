@@ -330,6 +330,7 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
   uint32_t* s_cnt = s_dyn;                                  // [1 << FINE_MAX_BITS] counts, then running cursors
   uint32_t* s_stage = s_dyn + (1 << FINE_MAX_BITS);          // [FINE_STAGE]
   __shared__ uint32_t s_wave[FINE_T / 64];
+  __shared__ uint32_t s_wmax[FINE_T / 64];
   const uint32_t bin = blockIdx.x;
   const uint32_t nfine = 1u << fb;
   const uint32_t per = (nfine + FINE_T - 1) / FINE_T;        // consecutive buckets per thread (<= 2)
@@ -337,6 +338,14 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
   const uint32_t cnt_bin = end - begin;
   const bool staged = cnt_bin <= (uint32_t)FINE_STAGE;   // the bin fits the threads' registers (and the LDS staging)
   const uint32_t imask = (1u << idx_bits) - 1u;
+#ifdef MSMZ_EXP_STAMPS
+  uint64_t ts[8];
+  int nts = 0;
+#define MSMZ_STAMP() ts[nts++] = __builtin_amdgcn_s_memtime()
+#else
+#define MSMZ_STAMP() (void)0
+#endif
+  MSMZ_STAMP();
   for (uint32_t f = threadIdx.x; f < nfine; f += FINE_T) s_cnt[f] = 0;
   // the bin's entries: all loads of a thread are issued back to back (the bin is read ONCE)
   uint32_t v[FINE_PER];
@@ -348,14 +357,21 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
     }
   }
   __syncthreads();
+  MSMZ_STAMP();   // 1: loads issued + zeroing + barrier
+  // histogram; on the staged path the atomic's return value IS the entry's rank inside its bucket (kept in a register),
+  // so no second round of atomics is needed: position = bucket offset + rank
+  uint32_t rank[FINE_PER];
   if (staged) {
 #pragma unroll
-    for (int j = 0; j < FINE_PER; j++)
-      if ((uint32_t)j * FINE_T + threadIdx.x < cnt_bin) atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
+    for (int j = 0; j < FINE_PER; j++) {
+      rank[j] = 0;
+      if ((uint32_t)j * FINE_T + threadIdx.x < cnt_bin) rank[j] = atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
+    }
   } else {
     for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
   }
   __syncthreads();
+  MSMZ_STAMP();   // 2: loads arrived + rank atomics
   uint32_t mine = 0, mx = 0, cnts[2] = {0, 0};
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t f = threadIdx.x * per + j;
@@ -372,7 +388,18 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
     const uint32_t y = __shfl_up(x, d, 64);
     if (lane >= d) x += y;
   }
-  if (lane == 63) s_wave[wave] = x;
+  // (the largest bucket of the bin: reduced over the workgroup first -- one global atomic per workgroup, not per wave:
+  // thousands of atomics on ONE address drain at ~90 per microsecond)
+  uint32_t wmx = mx;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(wmx, d, 64);
+    wmx = o > wmx ? o : wmx;
+  }
+  if (lane == 63) {
+    s_wave[wave] = x;
+    s_wmax[wave] = wmx;
+  }
   __syncthreads();
   uint32_t wbase = 0;
   for (int w2 = 0; w2 < wave; w2++) wbase += s_wave[w2];
@@ -380,14 +407,19 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t f = threadIdx.x * per + j;
     if (f < nfine) {
-      s_cnt[f] = ex;                                         // becomes the running cursor of bucket f
+      s_cnt[f] = ex;                                         // the bucket's offset (running cursor on the unstaged path)
       off[(size_t)bin * nfine + f] = begin + ex;
       ex += cnts[j & 1];
     }
   }
-  if (mx > 1) atomicMax(max_bucket, mx);
+  if (threadIdx.x == 0) {
+    uint32_t bmx = 0;
+    for (int w2 = 0; w2 < FINE_T / 64; w2++) bmx = s_wmax[w2] > bmx ? s_wmax[w2] : bmx;
+    if (bmx > 1) atomicMax(max_bucket, bmx);
+  }
   if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
   __syncthreads();
+  MSMZ_STAMP();   // 3: scan + off stores
   auto to_ref = [&](uint32_t pv) {
     uint32_t idx = pv & imask;
     if (idx >= n_half) idx += endo_delta;   // endomorphism half: record index in the point set
@@ -397,13 +429,23 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
 #pragma unroll
     for (int j = 0; j < FINE_PER; j++) {
       if ((uint32_t)j * FINE_T + threadIdx.x < cnt_bin) {
-        const uint32_t pos = atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
+        const uint32_t pos = s_cnt[v[j] >> (idx_bits + 1)] + rank[j];
         if (STAGE) s_stage[pos] = to_ref(v[j]); else refs[begin + pos] = to_ref(v[j]);
       }
     }
     if (STAGE) {
       __syncthreads();
+      MSMZ_STAMP();   // 4: placement in LDS
       for (uint32_t p = threadIdx.x; p < cnt_bin; p += FINE_T) refs[begin + p] = s_stage[p];
+      MSMZ_STAMP();   // 5: copy-out issued
+#ifdef MSMZ_EXP_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)");
+      MSMZ_STAMP();   // 6: stores drained
+      if (threadIdx.x == 0 && (bin == 0 || bin == 300))
+        printf("k_fine bin %u cnt %u: load+zero %llu  hist %llu  scan %llu  place %llu  copy-issue %llu  drain %llu  (cycles)\n", bin, cnt_bin,
+               (unsigned long long)(ts[1] - ts[0]), (unsigned long long)(ts[2] - ts[1]), (unsigned long long)(ts[3] - ts[2]),
+               (unsigned long long)(ts[4] - ts[3]), (unsigned long long)(ts[5] - ts[4]), (unsigned long long)(ts[6] - ts[5]));
+#endif
     }
   } else {
     // a bin too large for the LDS staging (heavily repeated scalars): second read, scattered stores
