@@ -684,10 +684,10 @@ class Engine : public IEngine {
       if ((st = tilecnt_.ensure((size_t)tiles * nbins * 2))) return st;
       if (pl.glv) {
         if constexpr (Fr::HAS_GLV)
-          hipLaunchKernelGGL((k_hist<Fr, true>), dim3(tiles), dim3(256), (size_t)nbins * 4, stream_, d_counts,
+          hipLaunchKernelGGL((k_hist<Fr, true>), dim3(tiles), dim3(COARSE_T), (size_t)nbins * 4, stream_, d_counts,
                              tilecnt_.as<uint16_t>(), d_meta, d_scalars, g, nbins);
       } else {
-        hipLaunchKernelGGL((k_hist<Fr, false>), dim3(tiles), dim3(256), (size_t)nbins * 4, stream_, d_counts,
+        hipLaunchKernelGGL((k_hist<Fr, false>), dim3(tiles), dim3(COARSE_T), (size_t)nbins * 4, stream_, d_counts,
                            tilecnt_.as<uint16_t>(), d_meta, d_scalars, g, nbins);
       }
       mark(pl);  // 1

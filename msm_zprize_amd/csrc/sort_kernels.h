@@ -20,8 +20,8 @@
 
 namespace msmz {
 
-constexpr int COARSE_T = 256;
-constexpr int COARSE_ITEMS = 8;                        // half-scalars (= entries per window) per thread
+constexpr int COARSE_T = 1024;
+constexpr int COARSE_ITEMS = 2;                        // half-scalars (= entries per window) per thread
 constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // entries per window staged by one workgroup
 constexpr int COARSE_MAX_BINS = 512;                   // bins per window (top window: incl. its sub-windows) the staging supports
 constexpr int SORT_MAX_BINS = 8192;                    // all windows: k_coarse keeps 3 words per bin in LDS (96 KB)
@@ -130,13 +130,13 @@ __device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_
 // bound: the host then repeats the MSM with one more bit), |= 4 when a scalar is not below the group order
 // (scalarsFromBytes' precondition, checked here instead of in a serial host loop).
 template <class Fr, bool GLV>
-__global__ void __launch_bounds__(256) k_hist(uint32_t* counts, uint16_t* tile_counts, MsmMeta* meta, const uint32_t* scalars,
+__global__ void __launch_bounds__(COARSE_T) k_hist(uint32_t* counts, uint16_t* tile_counts, MsmMeta* meta, const uint32_t* scalars,
                                               SortGeom g, uint32_t nbins) {
   extern __shared__ uint32_t s_hist[];
   constexpr int HALVES = GLV ? 2 : 1;
   constexpr int PER = COARSE_ITEMS / HALVES;   // scalars per thread: one workgroup = one tile of k_coarse
   const uint32_t L = 1u << (g.c - 1);
-  for (uint32_t b = threadIdx.x; b < nbins; b += 256) s_hist[b] = 0;
+  for (uint32_t b = threadIdx.x; b < nbins; b += COARSE_T) s_hist[b] = 0;
   __syncthreads();
   uint32_t bad = 0;
   // all of the thread's scalars are requested before any is sliced (one memory latency, not PER)
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) k_hist(uint32_t* counts, uint16_t* tile_c
   uint32_t idx[PER];
 #pragma unroll
   for (int it = 0; it < PER; it++) {
-    idx[it] = (blockIdx.x * PER + it) * 256 + threadIdx.x;
+    idx[it] = (blockIdx.x * PER + it) * COARSE_T + threadIdx.x;
     if (idx[it] < g.n) {
       if (!ds[it].load(scalars, idx[it])) bad |= 4u;
     } else {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_hist(uint32_t* counts, uint16_t* tile_c
   if (bad) atomicOr(&meta->error, bad);
   __syncthreads();
   uint16_t* row = tile_counts + (size_t)blockIdx.x * nbins;
-  for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
+  for (uint32_t b = threadIdx.x; b < nbins; b += COARSE_T) {
     const uint32_t v = s_hist[b];
     row[b] = (uint16_t)v;             // <= COARSE_TILE entries of a tile fall into one bin
     if (v) atomicAdd(&counts[b], v);
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
       }
     }
     uint32_t total;
-    uint32_t ex = block_exclusive_scan(sum, &total, s_wave);
+    uint32_t ex = block_exclusive_scan<COARSE_T>(sum, &total, s_wave);
     for (uint32_t q = 0; q < per; q++) {
       const uint32_t b = b0 + q;
       if (b < nbins) {
@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
 #ifdef MSMZ_EXP_STAMPS
   uint64_t ts[8];
   int nts = 0;
+  const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
 #define MSMZ_STAMP() ts[nts++] = __builtin_amdgcn_s_memtime()
 #else
 #define MSMZ_STAMP() (void)0
@@ -441,6 +442,8 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
 #ifdef MSMZ_EXP_STAMPS
       asm volatile("s_waitcnt vmcnt(0)");
       MSMZ_STAMP();   // 6: stores drained
+      if (threadIdx.x == 0)
+        printf("WG %u rt0 %llu rt1 %llu\n", bin, (unsigned long long)rt0, (unsigned long long)__builtin_amdgcn_s_memrealtime());
       if (threadIdx.x == 0 && (bin == 0 || bin == 300))
         printf("k_fine bin %u cnt %u: load+zero %llu  hist %llu  scan %llu  place %llu  copy-issue %llu  drain %llu  (cycles)\n", bin, cnt_bin,
                (unsigned long long)(ts[1] - ts[0]), (unsigned long long)(ts[2] - ts[1]), (unsigned long long)(ts[3] - ts[2]),
