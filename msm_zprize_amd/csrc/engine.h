@@ -577,13 +577,26 @@ class Engine : public IEngine {
       g.spread = c - 1 - g.t_top;
       if (g.spread > 3) g.spread = 3;
       const int ib = ceil_log2_u64(M < 2 ? 2 : M);
-      int fbm = 31 - ib > FINE_MAX_BITS ? FINE_MAX_BITS : 31 - ib;
-      if (fb_cap_ > 0 && fbm > fb_cap_) fbm = fb_cap_;
-      const int fbx = (c - 1) < fbm ? (c - 1) : fbm;
+      (void)ib;
+      const int fbx = fine_bits(c, M);
       while (g.spread > 0 && ((g.L >> fbx) << g.spread) > (uint32_t)COARSE_MAX_BINS) g.spread--;
     }
     g.Keff = g.K - 1 + (1 << g.spread);
     return g;
+  }
+
+  // Fine bits of the two-level sort = log2(buckets per coarse bin): as many as (1) the packed word leaves beside the
+  // index and the sign, (2) k_fine's counters hold, and (3) keep an average bin inside k_fine's LDS staging (a bin of
+  // 2^fb buckets holds ~M 2^fb / L entries; beyond FINE_STAGE it falls back to scattered stores: 3x slower).
+  int fine_bits(int c, uint32_t M) const {
+    const int idx_bits = ceil_log2_u64(M < 2 ? 2 : M);
+    int fb = 31 - idx_bits;
+    if (fb > FINE_MAX_BITS) fb = FINE_MAX_BITS;
+    if (fb_cap_ > 0 && fb > fb_cap_) fb = fb_cap_;
+    if (fb > c - 1) fb = c - 1;
+    const uint64_t L = 1ull << (c - 1);
+    while (fb > 0 && (((uint64_t)M << fb) / L) * 10 > (uint64_t)FINE_STAGE * 9) fb--;
+    return fb;
   }
 
   // Default window size.  Large inputs (M >= 2^19) are throughput-bound: c = log2 M - 3 capped at 17, stepped
@@ -661,10 +674,7 @@ class Engine : public IEngine {
     // packed word = fine bucket bits | negate | index: the narrower the index, the more fine bits fit, the
     // fewer (and longer) coarse runs the scatter writes
     const int idx_bits = ceil_log2_u64(M < 2 ? 2 : M);
-    int fb_max = 31 - idx_bits;
-    if (fb_max > FINE_MAX_BITS) fb_max = FINE_MAX_BITS;
-    if (fb_cap_ > 0 && fb_max > fb_cap_) fb_max = fb_cap_;
-    const int fb = (c - 1) < fb_max ? (c - 1) : fb_max;
+    const int fb = fine_bits(c, M);
     const uint32_t ncb = L >> fb;
     const uint32_t nbins = (uint32_t)pl.Keff * ncb;
     const bool sort2 = !force_atomic_sort_ && fb >= 0 && M <= (1u << 24) && (ncb << pl.spread) <= (uint32_t)COARSE_MAX_BINS &&
@@ -923,17 +933,21 @@ class Engine : public IEngine {
     // ---- plan: descriptors of every pair of every round + what is left of each bucket (plan_kernels.h)
     const int ev_plan0 = pl.ei;
     mark(pl);
-    const uint32_t n_chunks = (nb + PLAN_CHUNK - 1) / PLAN_CHUNK;
+    // buckets per plan workgroup: at most PLAN_CHUNK, fewer when the windows have few (long) buckets, so that the plan
+    // still spreads over ~4 workgroups per CU
+    uint32_t chunk = PLAN_CHUNK;
+    while (chunk > 64 && (nb + chunk - 1) / chunk < 1024) chunk >>= 1;
+    const uint32_t n_chunks = (nb + chunk - 1) / chunk;
     // chunk totals per round, then the per-workgroup scratch of the rounds beyond PLAN_RL
     const size_t pair_words = (size_t)n_chunks * (PLAN_RMAX - PLAN_RL) * PLAN_T;
     if ((st = rscan_.ensure(((size_t)PLAN_RMAX * n_chunks + pair_words) * 4))) return st;
     if ((st = desc_.ensure((size_t)pl.K * pl.M * 8))) return st;
     if ((st = bfin_.ensure((size_t)nb * 16))) return st;
     hipLaunchKernelGGL(k_plan_count, dim3(n_chunks), dim3(PLAN_T), 0, stream_, rscan_.as<uint32_t>(), off_.as<uint32_t>(),
-                       nb, n_chunks, d_meta, tail_skip_);
+                       nb, n_chunks, d_meta, tail_skip_, chunk);
     hipLaunchKernelGGL(k_plan_emit, dim3(n_chunks), dim3(PLAN_T), 0, stream_, desc_.as<uint2>(), bfin_.as<uint4>(),
                        d_meta, rscan_.as<uint32_t>(), off_.as<uint32_t>(), refs_.as<uint32_t>(), nb, n_chunks,
-                       tail_skip_, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks);
+                       tail_skip_, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks, chunk);
     MSMZ_HIP(hipGetLastError());
     if ((st = fetch_meta(pl))) return st;      // the ONE host round trip before the final fetch
     if (h_meta_->error & 4u) return MSMZ_ERR_RANGE;

@@ -45,16 +45,20 @@ __device__ __forceinline__ uint32_t pairs_in_round(uint32_t size, int r) {   // 
 }
 
 // chunk_pairs[r * n_chunks + chunk] = pairs of round r in the chunk's buckets, r < PLAN_RMAX
+// `chunk` <= PLAN_CHUNK buckets per workgroup (the host picks it so that there are enough workgroups for the GPU even
+// when a window has few, long buckets).
 static __global__ void __launch_bounds__(PLAN_T) k_plan_count(uint32_t* chunk_pairs, const uint32_t* off, uint32_t nb,
-                                                              uint32_t n_chunks, const MsmMeta* meta, int tail_skip) {
+                                                              uint32_t n_chunks, const MsmMeta* meta, int tail_skip,
+                                                              uint32_t chunk) {
   __shared__ uint32_t s_tot[PLAN_RMAX];
   const int R = plan_rounds(meta->max_bucket, tail_skip);
   if (threadIdx.x < PLAN_RMAX) s_tot[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t g0 = blockIdx.x * PLAN_CHUNK + threadIdx.x * PLAN_PER;
+  const uint32_t g0 = blockIdx.x * chunk + threadIdx.x * PLAN_PER;
   uint32_t size[PLAN_PER];
 #pragma unroll
-  for (int q = 0; q < PLAN_PER; q++) size[q] = g0 + q < nb ? off[g0 + q + 1] - off[g0 + q] : 0u;
+  for (int q = 0; q < PLAN_PER; q++)
+    size[q] = (threadIdx.x * PLAN_PER + q < chunk && g0 + q < nb) ? off[g0 + q + 1] - off[g0 + q] : 0u;
   for (int r = 0; r < R; r++) {
     uint32_t s = 0;
 #pragma unroll
@@ -70,7 +74,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_count(uint32_t* chunk_pa
 static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4* bfin, MsmMeta* meta,
                                                              const uint32_t* chunk_pairs, const uint32_t* off,
                                                              const uint32_t* refs, uint32_t nb, uint32_t n_chunks,
-                                                             int tail_skip, uint32_t* pair_scratch) {
+                                                             int tail_skip, uint32_t* pair_scratch, uint32_t chunk) {
   __shared__ uint32_t s_before[PLAN_RMAX];              // pairs of round r in the chunks before this one
   __shared__ uint32_t s_total[PLAN_RMAX];               // pairs of round r
   __shared__ uint32_t s_rbase[PLAN_RMAX + 1];           // first record of round r's result array
@@ -95,8 +99,8 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     s_before[threadIdx.x] = 0;
     s_total[threadIdx.x] = 0;
   }
-  const uint32_t g0 = blockIdx.x * PLAN_CHUNK;
-  const uint32_t nbk = nb - g0 < (uint32_t)PLAN_CHUNK ? nb - g0 : (uint32_t)PLAN_CHUNK;   // buckets of this chunk
+  const uint32_t g0 = blockIdx.x * chunk;
+  const uint32_t nbk = nb - g0 < chunk ? nb - g0 : chunk;   // buckets of this chunk
   for (uint32_t b = threadIdx.x; b <= nbk; b += PLAN_T) s_start[b] = off[g0 + b];
   __syncthreads();
   for (int r = 0; r < R; r++) {
