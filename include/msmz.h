@@ -56,7 +56,9 @@ typedef struct msmz_opts {
   int32_t safe;     /* 1 = msm (handles equal / opposite / infinity points), 0 = msmUnsafe */
   int32_t buckets;  /* MSMZ_BUCKETS_AFFINE (batched-affine) or MSMZ_BUCKETS_PROJECTIVE (msmProjective) */
   int32_t timing;   /* 1 = fill msmz_log stage timings with HIP events (the reference's tic/toc log) */
-  int32_t reserved[3];
+  int32_t reserved[3]; /* reserved[0] = 1: first level of the bucket reduction by batched-affine additions
+                        * (reduceBucketsAffine, msm-batched-affine-single-thread.ts:522-667) instead of XYZZ running
+                        * sums; same result, measured slower on MI355X (profiles/r02_reduce_ab.txt): default 0 */
 } msmz_opts;
 
 /* Stage timings + counts, the analogue of the `log` array msm() returns (msm-common.ts:192-230). */

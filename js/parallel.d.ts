@@ -6,7 +6,7 @@ export type CurveParams = {
 };
 export type BigintPoint = { x: bigint; y: bigint; isZero?: boolean };
 export interface DeviceArray extends Array<DeviceArray> { readonly n: number; readonly kind: "points" | "scalars"; free(): void }
-export type MsmOptions = { c?: number; glv?: boolean | number; useSafeAdditions?: boolean };
+export type MsmOptions = { c?: number; glv?: boolean | number; useSafeAdditions?: boolean; reduceAffine?: boolean };
 export type MsmResult = { result: BigintPoint; log: any[][]; stats: Record<string, any> };
 export interface ParallelApi {
   randomPointsFast(n: number, options?: { seed?: bigint | number }): Promise<DeviceArray>;

@@ -104,6 +104,7 @@ function createCurve(params, kind) {
       safe: options.useSafeAdditions !== undefined ? Number(options.useSafeAdditions) : safe,
       buckets,
       timing: verbose ? 1 : 0,
+      reduceAffine: options.reduceAffine ? 1 : 0, // batched-affine first reduction level (reduceBucketsAffine)
     };
     const s = scalars instanceof DeviceArray ? scalars.handle : scalars; // Buffer = host scalars
     const r = N.msm(ctx, points.handle, s, n, fb, opts);

@@ -1,8 +1,8 @@
 // One tree round of batched-affine bucket additions (rows a6 / a12 of SURVEY.md section 8).  Included by kernels.h.
 //
-// Pair t of round r adds the two operands its descriptor names (plan_kernels.h; the schedule is the reference's,
-// msm-batched-affine.ts:232-247) and writes record base_r + t of the round's compact, chunk-interleaved result
-// array (limb form, kernels.h).  Round 0 gathers the original points.
+// Pair t of a launch adds the two operands its descriptor dsc[t] names (plan_kernels.h; the schedule of the tree rounds
+// is the reference's, msm-batched-affine.ts:232-247) and writes record out_base + t of the launch's compact,
+// chunk-interleaved result array (kernels.h).  Round 0 gathers the original points.
 //
 // Batch inversion (Montgomery's trick) on two levels:
 //   * each thread walks B pairs like batchAddUnsafeNew (curve-affine.ts:463-522): the forward pass keeps a running
@@ -34,16 +34,13 @@ namespace msmz {
 enum { PK_NONE = 0, PK_ADD = 1, PK_DBL = 2, PK_TAKE_A = 3, PK_TAKE_B = 4, PK_INF = 5 };
 
 template <class F, int T, bool SAFE, int OCC, int BMAX>
-__global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint2* desc, int r,
-                                                      int B, MsmMeta* meta) {
+__global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uint32_t* points, const uint2* dsc,
+                                                      uint32_t out_base, uint32_t total, int B, MsmMeta* meta) {
   // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
   // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
   __shared__ int32_t tree[F::N * T];
   __shared__ uint8_t s_kind[SAFE ? BMAX * T : 1];
   constexpr int N = F::N;
-  const uint32_t out_base = meta->round_base[r];
-  const uint32_t total = meta->round_pairs[r];
-  const uint2* dsc = desc + out_base;
   const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
 
   Fe<F> prefix;

@@ -164,7 +164,7 @@ class Engine : public IEngine {
   ~Engine() override {
     (void)hipSetDevice(device_);
     for (auto& kv : handles_) (void)hipFree(kv.second.dev);
-    for (DevBuf* b : {&tilecnt_, &final_, &desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+    for (DevBuf* b : {&f2desc_, &tilecnt_, &final_, &desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
                       &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
       b->release();
     if (h_meta_) (void)hipHostFree(h_meta_);
@@ -925,7 +925,9 @@ class Engine : public IEngine {
     if (st) return st;
     // location words hold a record index in 30 bits
     if ((uint64_t)pl.K * pl.M >= (1ull << 30)) return MSMZ_ERR_ARG;
-    if ((st = slots_.ensure(((size_t)pl.K * pl.M + 64) * SlotFmt<F>::WORDS * 4))) return st;   // whole groups of 64 records
+    // whole groups of 64 records; + the records of the batched-affine first reduction level when it is selected
+    const size_t f2_records = opt.reserved[0] == 1 ? (size_t)13 * pl.Keff * ((pl.L + 1) / 2) + 256 : 0;
+    if ((st = slots_.ensure(((size_t)pl.K * pl.M + 64 + f2_records) * SlotFmt<F>::WORDS * 4))) return st;
     if ((st = sort_phase(pl, d_scalars))) return st;
     const uint32_t nb = pl.nb;
     MsmMeta* d_meta = meta_.as<MsmMeta>();
@@ -943,11 +945,14 @@ class Engine : public IEngine {
     if ((st = rscan_.ensure(((size_t)PLAN_RMAX * n_chunks + pair_words) * 4))) return st;
     if ((st = desc_.ensure((size_t)pl.K * pl.M * 8))) return st;
     if ((st = bfin_.ensure((size_t)nb * 16))) return st;
+    // the batched-affine first reduction level (opt.reserved[0] = 1) wants ONE sum per bucket: no rounds skipped
+    const bool f2 = opt.reserved[0] == 1 && pl.L >= 2;
+    const int tail_skip = f2 ? 0 : tail_skip_;
     hipLaunchKernelGGL(k_plan_count, dim3(n_chunks), dim3(PLAN_T), 0, stream_, rscan_.as<uint32_t>(), off_.as<uint32_t>(),
-                       nb, n_chunks, d_meta, tail_skip_, chunk);
+                       nb, n_chunks, d_meta, tail_skip, chunk);
     hipLaunchKernelGGL(k_plan_emit, dim3(n_chunks), dim3(PLAN_T), 0, stream_, desc_.as<uint2>(), bfin_.as<uint4>(),
                        d_meta, rscan_.as<uint32_t>(), off_.as<uint32_t>(), refs_.as<uint32_t>(), nb, n_chunks,
-                       tail_skip_, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks, chunk);
+                       tail_skip, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks, chunk);
     MSMZ_HIP(hipGetLastError());
     if ((st = fetch_meta(pl))) return st;      // the ONE host round trip before the final fetch
     if (h_meta_->error & 4u) return MSMZ_ERR_RANGE;
@@ -963,7 +968,8 @@ class Engine : public IEngine {
     for (int r = 0; r < R; r++) {
       const uint32_t pairs = h_round_pairs_[r];
       if (pairs == 0) continue;
-      launch_batch_add(pairs, opt.safe != 0, d_points, r, d_meta);
+      launch_batch_add(pairs, opt.safe != 0, d_points, desc_.as<uint2>() + h_meta_->round_base[r], h_meta_->round_base[r],
+                       d_meta);
       mark(pl);
     }
     const int ev_acc_end = pl.ei;
@@ -971,11 +977,17 @@ class Engine : public IEngine {
 
     // ---- bucket reduction: level 1 from affine bucket sums, then XYZZ levels down to one entry per window
     using P = WeierPolicy<F>;
-    const uint32_t S1 = first_group_size(pl);
+    uint32_t S1 = first_group_size(pl);
+    if (f2) {   // the weight-L bucket is folded into element L/2, which must be the FIRST element of its group
+      if (S1 > 8) S1 = 8;
+      while (S1 > 1 && S1 * 2 > pl.L) S1 >>= 1;
+    }
     const uint32_t groups = (pl.L + S1 - 1) / S1;   // elements are weights 0..L-1 (weight L folded into L/2)
     if ((st = red_[0].ensure((size_t)pl.Keff * groups * XW * 4))) return st;
     if ((st = red_[1].ensure((size_t)pl.Keff * groups * XW * 4))) return st;
-    {
+    if (f2) {
+      if ((st = reduce_first_affine(pl, d_points, S1, groups, n_pairs, d_meta))) return st;
+    } else {
       uint32_t total = pl.Keff * groups;
       hipLaunchKernelGGL((k_reduce_first<F>), dim3((total + 127) / 128), dim3(128), 0, stream_,
                          red_[0].as<uint32_t>(), red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points,
@@ -1110,7 +1122,62 @@ class Engine : public IEngine {
     fe_unpack<F>(p.T, w + 3 * NW);
   }
 
-  void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, int r, MsmMeta* d_meta) {
+  // Batched-affine first level of the bucket reduction (reduce_affine.h): S - 1 chain steps and
+  // a short pair tree, every launch over Keff * groups (x pairs per group) additions; results behind the tree rounds'
+  // records.  Leaves the scaled (row, tri) XYZZ records in red_[0] / red_[1] like k_reduce_first.
+  int reduce_first_affine(const Plan& pl, const uint32_t* d_points, uint32_t S, uint32_t groups, uint64_t tree_pairs,
+                          MsmMeta* d_meta) {
+    F2Geom g;
+    memset(&g, 0, sizeof(g));
+    g.L = pl.L;
+    g.S = S;
+    g.groups = groups;
+    g.NG = (uint32_t)pl.Keff * groups;
+    g.inf_slot = (uint32_t)((tree_pairs + 63) / 64 * 64);
+    g.out0 = g.inf_slot + 64;
+    uint32_t n_launch = 0, dsum = 0, osum = 0;
+    for (uint32_t step = 1; step < S; step++) {
+      g.ppg[n_launch] = 1;
+      g.desc_off[n_launch] = dsum;
+      g.out_off[n_launch] = osum;
+      dsum += g.NG;
+      osum += g.NG;
+      n_launch++;
+    }
+    for (uint32_t n = S - 1; n > 1; n = n / 2 + (n & 1)) {
+      g.ppg[n_launch] = n / 2;
+      g.desc_off[n_launch] = dsum;
+      g.out_off[n_launch] = osum;
+      dsum += g.NG * (n / 2);
+      osum += g.NG * (n / 2);
+      n_launch++;
+    }
+    g.n_launches = n_launch;
+    g.desc_off[n_launch] = dsum;   // (row, tri) locations of every group
+    dsum += g.NG;
+    if ((uint64_t)g.out0 + osum + 64 >= (1ull << 30)) return MSMZ_ERR_ARG;
+    int st;
+    if ((st = f2desc_.ensure((size_t)dsum * 8))) return st;
+    // slots_ may have to grow: its contents (the tree rounds' results) must survive -> it was sized for this in advance
+    if (((size_t)g.out0 + osum + 64) * SlotFmt<F>::WORDS * 4 > slots_.bytes) return MSMZ_ERR_HIP;
+    MSMZ_HIP(hipMemsetAsync(slots_.as<uint32_t>() + slot_words(g.inf_slot), 0, (size_t)64 * SlotFmt<F>::WORDS * 4, stream_));
+    hipLaunchKernelGGL(k_reduce_affine_desc, dim3((g.NG + 255) / 256), dim3(256), 0, stream_, f2desc_.as<uint2>(),
+                       bfin_.as<uint4>(), g);
+    for (uint32_t i = 0; i < n_launch; i++)
+      launch_batch_add(g.NG * g.ppg[i], true, d_points, f2desc_.as<uint2>() + g.desc_off[i], g.out0 + g.out_off[i], d_meta);
+    hipLaunchKernelGGL((k_reduce_affine_finish<F>), dim3((g.NG + 127) / 128), dim3(128), 0, stream_, red_[0].as<uint32_t>(),
+                       red_[1].as<uint32_t>(), slots_.as<uint32_t>(), d_points, f2desc_.as<uint2>() + g.desc_off[n_launch],
+                       bfin_.as<uint4>(), g);
+    MSMZ_HIP(hipGetLastError());
+    return MSMZ_OK;
+  }
+  static size_t slot_words(uint32_t rec) {   // host twin of slot_offset<F> (rec a multiple of 64)
+    return (size_t)(rec >> 6) * (SlotFmt<F>::CH * 64) * 4;
+  }
+
+  // one launch of batched-affine additions: pairs `dsc[0 .. pairs)`, results in slot records out_base + t
+  void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint2* dsc, uint32_t out_base,
+                        MsmMeta* d_meta) {
     constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
     // pairs per thread: as many as keep >= ~2 workgroups per CU in flight, capped at BMAX
     int B = 1;
@@ -1120,10 +1187,10 @@ class Engine : public IEngine {
     if constexpr (!TE) {
       if (safe) {
         hipLaunchKernelGGL((k_batch_add<F, T, true, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
-                           d_points, desc_.as<uint2>(), r, B, d_meta);
+                           d_points, dsc, out_base, pairs, B, d_meta);
       } else {
         hipLaunchKernelGGL((k_batch_add<F, T, false, OCC, BMAX>), grid, block, 0, stream_, slots_.as<uint32_t>(),
-                           d_points, desc_.as<uint2>(), r, B, d_meta);
+                           d_points, dsc, out_base, pairs, B, d_meta);
       }
     }
   }
@@ -1231,7 +1298,7 @@ class Engine : public IEngine {
   int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
   bool fine_attr_set_ = false;
   bool fine_stage_ = env_int("MSMZ_FINE_STAGE", 1) != 0;   // unstaged (scattered 4-byte stores): measured 277 vs 148 us
-  DevBuf tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  DevBuf f2desc_, tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};
   int basic_ev_[4] = {};

@@ -42,9 +42,9 @@
 
 #define MSMZ_INST_BATCH(F, Fr, PFX)                                                                               \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, true, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(              \
-      uint32_t*, const uint32_t*, const uint2*, int, int, MsmMeta*);                                             \
+      uint32_t*, const uint32_t*, const uint2*, uint32_t, uint32_t, int, MsmMeta*);                              \
   PFX template __global__ void k_batch_add<F, MSMZ_BATCH_T, false, MSMZ_BATCH_OCC, MSMZ_BATCH_BMAX>(             \
-      uint32_t*, const uint32_t*, const uint2*, int, int, MsmMeta*);
+      uint32_t*, const uint32_t*, const uint2*, uint32_t, uint32_t, int, MsmMeta*);
 
 #define MSMZ_INST_POLICY(P, PFX)                                                                                 \
   PFX template __global__ void k_reduce_quad<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, uint32_t, \
@@ -61,6 +61,8 @@
 #define MSMZ_INST_REDUCE(F, Fr, PFX)                                                                              \
   PFX template __global__ void k_reduce_first<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
                                                  const uint4*, uint32_t, uint32_t, uint32_t, uint32_t);           \
+  PFX template __global__ void k_reduce_affine_finish<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,  \
+                                                         const uint2*, const uint4*, F2Geom);                     \
   MSMZ_INST_POLICY(WeierPolicy<F>, PFX)
 
 #define MSMZ_INST_REDUCE_TE(F, Fr, PFX) MSMZ_INST_POLICY(TePolicy<F>, PFX)

@@ -1243,3 +1243,5 @@ __global__ void __launch_bounds__(REDUCE_TAIL_T, 1) k_reduce_tail(uint32_t* r0, 
 
 
 }  // namespace msmz
+
+#include "reduce_affine.h"

@@ -160,6 +160,7 @@ class _Parallel:
         opts.safe = int(options.get("useSafeAdditions", safe))
         opts.buckets = buckets
         opts.timing = 1 if verbose else 0
+        opts.reserved[0] = int(options.get("reduceAffine", 0))   # 1: batched-affine first reduction level (reduceBucketsAffine)
         fb = self._c.fe_bytes
         out = C.create_string_buffer(2 * fb)
         inf = C.c_int()

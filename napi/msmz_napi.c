@@ -235,6 +235,7 @@ static napi_value Msm(napi_env env, napi_callback_info info) {
     o.safe = opt_i32(env, argv[5], "safe");
     o.buckets = opt_i32(env, argv[5], "buckets");
     o.timing = opt_i32(env, argv[5], "timing");
+    o.reserved[0] = opt_i32(env, argv[5], "reduceAffine");
   }
   void* data; napi_value xy;
   NAPI_CALL(env, napi_create_buffer(env, (size_t)(2 * fb), &data, &xy));

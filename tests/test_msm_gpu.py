@@ -344,3 +344,36 @@ def test_window_sizes_that_take_the_fallback_sort(curves):
         assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": glv, "c": c})["result"] == want, (glv, c)
     assert curve.Parallel.msmProjective(sc, pts, n, {"c": 22})["result"] == want
     pts.free(); sc.free()
+
+
+@pytest.mark.parametrize("label", WEIER)
+def test_batched_affine_bucket_reduction(curves, label):
+    """the reference's reduceBucketsAffine (msm-batched-affine-single-thread.ts:522-667,
+    doc/zprize22.md:317-358) as an option -- first reduction level by lock-step batched-affine running sums; must give
+    the same point as the default XYZZ reduction and the oracle for every window size (group sizes 2, 4, 8), with
+    empty buckets, repeated points (doublings inside the chain) and the safe / unsafe / GLV variants"""
+    curve = curves(label)
+    c = P.CURVES[label]
+    q = c["order"]
+    rng = random.Random(21)
+    for n, seed in ((1, 1), (5, 2), (300, 3), (2500, 4)):
+        pts = curve.Parallel.randomPointsFast(n, 7000 + seed)
+        sc = curve.Parallel.randomScalars(n, 7100 + seed)
+        want = _oracle(label, curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
+        for glv in (0, 1):
+            for cc in (0, 2, 3, 4, 6, 9, 12):
+                got = curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": glv, "c": cc, "reduceAffine": 1})["result"]
+                assert got == want, (n, glv, cc)
+            assert curve.Parallel.msm(sc, pts, n, False, {"glv": glv, "reduceAffine": 1})["result"] == want
+        pts.free(); sc.free()
+    # equal points in neighbouring buckets: the chain R = R + E hits P + P (doubling) and P + (-P)
+    g = c["generator"]
+    pt = _strip(c_oracle.scale(c, 0xABCDEF, {"x": g["x"], "y": g["y"], "isZero": False}))
+    neg = {"x": pt["x"], "y": c["modulus"] - pt["y"], "isZero": False}
+    points = [pt, pt, pt, neg, pt]
+    scalars = [1, 2, 3, 2, q - 1]
+    want = _oracle(label, scalars, points)
+    p2 = curve.Parallel.pointsFromBigints(points)
+    s2 = curve.Parallel.scalarsFromBigints(scalars)
+    for cc in (2, 3, 5):
+        assert curve.Parallel.msm(s2, p2, 5, False, {"glv": 0, "c": cc, "reduceAffine": 1})["result"] == want, cc
