@@ -3,22 +3,28 @@
 //
 //   k_points_to_mont     upload: canonical bytes -> lazy Montgomery residues (+ endomorphism copy)
 //                        (parallel.ts:97-112 pointsFromBytes, field-msm.ts:183-185, wasm/curve.ts:90-103)
-//   k_digits             GLV split + signed c-bit digits + bucket histogram
-//                        (msm-batched-affine.ts:149,172-200; scalar-glv.ts:105-128)
-//   k_scan_*             exclusive prefix sums: bucket offsets and per-round pair offsets
-//                        (msm-batched-affine.ts:411-435 integrateBucketCounts)
-//   k_scatter_coarse,    counting sort of point *indices* into bucket order in two LDS-staged passes (k_scatter is
-//   k_sort_fine          the one-pass atomic fallback)
-//                        (msm-batched-affine.ts:444-490 sortPoints -- which copies 116-byte points;
-//                        here 4-byte references are sorted and points are gathered on first use)
-//   k_batch_add          one tree round of batched-affine additions inside all buckets, with a
-//                        workgroup-wide Montgomery batch inversion (product tree in LDS, one wave-wide field
-//                        inversion per workgroup, fe_inverse_wave); results in chunk-interleaved slot arrays
+//   k_hist, k_bin_scan,  (sort_kernels.h) GLV split + signed c-bit digits + coarse-bin histogram, bin offsets, and the
+//   k_coarse, k_fine     counting sort of point *indices* into bucket order in two LDS-staged passes; the digits are
+//                        re-sliced from the scalars by every pass, never stored
+//                        (msm-batched-affine.ts:149,172-200 slicing; :411-435 integrateBucketCounts; :444-490 sortPoints
+//                        -- which copies 116-byte points; here 4-byte references are sorted and points are gathered
+//                        on first use)
+//   k_digits, k_scan_*,  fallback sort for window sizes whose coarse bins do not fit the LDS staging (digits
+//   k_scatter            materialized, one global atomic per entry); k_scan_* also serve the msmBasic path's chunk offsets
+//   k_plan_count,        (plan_kernels.h) the schedule of the tree rounds as data: rounds decided on the device, one
+//   k_plan_emit          {locA, locB} descriptor per addition (msm-batched-affine.ts:232-247), final locations per bucket
+//   k_batch_add          (batch_kernels.h) one tree round of batched-affine additions, with a workgroup-wide Montgomery
+//                        batch inversion (product tree in LDS, one wave-wide field inversion per workgroup,
+//                        fe_inverse_wave); results in chunk-interleaved slot arrays
 //                        (msm-batched-affine.ts:232-270; curve-affine.ts:376-522; inverse.ts:220-271)
 //   k_reduce_first,      bucket reduction  sum_l l*B_l  by grouped running sums in XYZZ coordinates: first level
-//   k_reduce_quad(16),   from the (partial) bucket sums, upper levels with a quad of lanes per group / per addition
+//   k_reduce_quad(16),   from the (partial) bucket sums, upper levels with a quad of lanes per group / per addition,
+//   k_reduce_tail,       the last levels in one launch; k_reduce_next = first level of the msmBasic path
 //   k_reduce_next        (msm-batched-affine.ts:544-571 reduceBucketsColumnProjective)
+//   k_reduce_affine_*    (reduce_affine.h) optional batched-affine first level (reduceBucketsAffine,
+//                        msm-batched-affine-single-thread.ts:522-667)
 //   k_bucket_accumulate  msmBasic path: buckets in XYZZ / extended coordinates (msm-basic.ts:106-128)
+//   k_test_*             (test_kernels.h) stage-level test hooks of include/msmz_test.h
 //
 // Bucket numbering: global bucket g = k*L + (l-1) for window k and digit l in [1, L], L = 2^(c-1).
 // Sorted references: ref = point_index | (negate << 31).
