@@ -22,7 +22,7 @@
 namespace msmz {
 
 #ifndef MSMZ_BATCH_BMAX
-#define MSMZ_BATCH_BMAX 32
+#define MSMZ_BATCH_BMAX 16
 #endif
 #ifdef MSMZ_EXP_NOMUL   // timing experiment (wrong results): the six products of an addition cost nothing
 #define BM_MUL(r, a, b) fe_add(r, a, b)

@@ -725,24 +725,18 @@ class Engine : public IEngine {
       mark(pl);  // 3
       MSMZ_HIP(hipGetLastError());
       {
-        if (fine_stage_) {
-          const size_t lds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
-          if (!fine_attr_set_) {   // the attribute is per device: set once per engine
-            // (seen once on a fresh box: the first call returned "invalid argument" and the next one succeeded)
-            if (hipFuncSetAttribute((const void*)k_fine<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-              (void)hipGetLastError();
-              MSMZ_HIP(hipFuncSetAttribute((const void*)k_fine<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            }
-            fine_attr_set_ = true;
+        const size_t lds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
+        if (!fine_attr_set_) {   // the attribute is per device: set once per engine
+          // (seen once on a fresh box: the first call returned "invalid argument" and the next one succeeded)
+          if (hipFuncSetAttribute((const void*)k_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            MSMZ_HIP(hipFuncSetAttribute((const void*)k_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           }
-          hipLaunchKernelGGL(k_fine<true>, dim3(nbins), dim3(FINE_T), lds, stream_, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                             &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins, idx_bits, n_half,
-                             pl.endo_delta);
-        } else {
-          hipLaunchKernelGGL(k_fine<false>, dim3(nbins), dim3(FINE_T), (size_t)(1 << FINE_MAX_BITS) * 4, stream_,
-                             refs_.as<uint32_t>(), off_.as<uint32_t>(), &d_meta->max_bucket, packed_.as<uint32_t>(),
-                             bins_.as<uint32_t>(), fb, nbins, idx_bits, n_half, pl.endo_delta);
+          fine_attr_set_ = true;
         }
+        hipLaunchKernelGGL(k_fine, dim3(nbins), dim3(FINE_T), lds, stream_, refs_.as<uint32_t>(), off_.as<uint32_t>(),
+                           &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins, idx_bits, n_half,
+                           pl.endo_delta);
       }
     } else {
       // fallback (window sizes whose coarse bins do not fit the LDS staging): digits materialized, one global
@@ -1179,7 +1173,8 @@ class Engine : public IEngine {
   void launch_batch_add(uint32_t pairs, bool safe, const uint32_t* d_points, const uint2* dsc, uint32_t out_base,
                         MsmMeta* d_meta) {
     constexpr int T = MSMZ_BATCH_T, OCC = MSMZ_BATCH_OCC, BMAX = MSMZ_BATCH_BMAX;
-    // pairs per thread: as many as keep >= ~2 workgroups per CU in flight, capped at BMAX
+    // pairs per thread: as many as keep >= ~2 workgroups per CU in flight, capped at BMAX = 16 (measured per round at
+    // 2^20: 7.6 M pairs B = 8..16, 3.7 M: 16, 1.8 M: 8, 0.9 M: 4, < 0.3 M: 2; 32 is slower everywhere)
     int B = 1;
     while (B < BMAX && (uint64_t)pairs >= (uint64_t)T * (B * 2) * batch_min_wgs_) B *= 2;
     if (batch_b_override_ > 0) B = batch_b_override_ < BMAX ? batch_b_override_ : BMAX;
@@ -1286,7 +1281,8 @@ class Engine : public IEngine {
 #endif
   uint32_t coarse_wgs_ = (uint32_t)env_int("MSMZ_COARSE_WGS", 2048);
   uint32_t batch_min_wgs_ = (uint32_t)env_int("MSMZ_BATCH_WGS", 512);
-  int tail_skip_ = env_int("MSMZ_TAIL_SKIP", 2);
+  // rounds left to the reduction's loader: at most 2 (a bucket's final-location record holds 4 partial sums)
+  int tail_skip_ = env_int("MSMZ_TAIL_SKIP", 2) > 2 ? 2 : env_int("MSMZ_TAIL_SKIP", 2);
   int chunk_shift_override_ = env_int("MSMZ_CHUNK_SHIFT", 0);
   int fb_cap_ = env_int("MSMZ_FB", 0);
   uint32_t s1_override_ = (uint32_t)env_int("MSMZ_S1", 0);
@@ -1297,7 +1293,6 @@ class Engine : public IEngine {
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
   int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
   bool fine_attr_set_ = false;
-  bool fine_stage_ = env_int("MSMZ_FINE_STAGE", 1) != 0;   // unstaged (scattered 4-byte stores): measured 277 vs 148 us
   DevBuf f2desc_, tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};

@@ -37,7 +37,7 @@
 #define MSMZ_BATCH_OCC 4
 #endif
 #ifndef MSMZ_BATCH_BMAX
-#define MSMZ_BATCH_BMAX 32
+#define MSMZ_BATCH_BMAX 16
 #endif
 
 #define MSMZ_INST_BATCH(F, Fr, PFX)                                                                               \

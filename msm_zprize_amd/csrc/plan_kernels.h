@@ -85,14 +85,6 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
   uint32_t* s_pair = pair_scratch + (size_t)blockIdx.x * (PLAN_RMAX - PLAN_RL) * PLAN_T;
   __shared__ uint32_t s_wave[PLAN_T / 64];
   __shared__ uint16_t s_owner[PLAN_TILE];              // chunk bucket of every pair of the current tile
-#ifdef MSMZ_EXP_STAMPS
-  uint64_t ts[12];
-  int nts = 0;
-#define MSMZ_PSTAMP() ts[nts++] = __builtin_amdgcn_s_memtime()
-#else
-#define MSMZ_PSTAMP() (void)0
-#endif
-  MSMZ_PSTAMP();
   const int R = plan_rounds(meta->max_bucket, tail_skip);
   const int RL = R < PLAN_RL ? R : PLAN_RL;
   if (threadIdx.x < PLAN_RMAX) {
@@ -121,7 +113,6 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     }
   }
   __syncthreads();
-  MSMZ_PSTAMP();   // 1: chunk totals
   if (threadIdx.x == 0) {
     uint32_t base = 0;
     for (int r = 0; r < PLAN_RMAX; r++) {
@@ -161,7 +152,6 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     }
   }
   __syncthreads();
-  MSMZ_PSTAMP();   // 2: per-round scans
   // location of the element at relative position `pos` of chunk bucket b before round r (see the header); prr = this
   // thread's running pair numbers for the rounds >= PLAN_RL (only meaningful on the bucket-by-bucket path)
   auto location = [&](uint32_t b, uint32_t st, uint32_t sz, uint32_t pos, int r) -> uint32_t {
@@ -202,7 +192,6 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
       __syncthreads();
     }
   }
-  MSMZ_PSTAMP();   // 3: descriptors of rounds < RL
   // rounds >= PLAN_RL (very long buckets) and the per-bucket records: bucket by bucket
 #pragma unroll 1
   for (int q = 0; q < PLAN_PER; q++) {
@@ -227,15 +216,6 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     bfin[g0 + b] = fin;
     for (int r = PLAN_RL; r < R; r++) s_pair[(r - PLAN_RL) * PLAN_T + threadIdx.x] += pairs_in_round(sz, r);   // -> next bucket
   }
-#ifdef MSMZ_EXP_STAMPS
-  MSMZ_PSTAMP();   // 4: bfin
-  asm volatile("s_waitcnt vmcnt(0)");
-  MSMZ_PSTAMP();
-  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
-    printf("k_plan_emit chunk %u: totals %llu  scans %llu  desc %llu  bfin %llu  drain %llu (cycles) R=%d np0=%u\n", blockIdx.x,
-           (unsigned long long)(ts[1] - ts[0]), (unsigned long long)(ts[2] - ts[1]), (unsigned long long)(ts[3] - ts[2]),
-           (unsigned long long)(ts[4] - ts[3]), (unsigned long long)(ts[5] - ts[4]), R, s_pref[0][PLAN_CHUNK]);
-#endif
 }
 
 }  // namespace msmz

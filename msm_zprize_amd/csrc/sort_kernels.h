@@ -291,11 +291,7 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
       for (int h = 0; h < HALVES; h++) {
         uint32_t ng;
         const uint32_t l = ds[s].next(h, k, g.c, L, ng);
-#ifdef MSMZ_EXP_COARSE_NORANK
-        if (l == 0xffffffffu) {
-#else
         if (l != 0) {
-#endif
           const uint32_t entry = (uint32_t)h * g.n + idx[s];
           const uint32_t bi = l - 1;
           const uint32_t bin = (entry & smask) * g.ncb + (bi >> g.fb);
@@ -311,9 +307,6 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
     // run is a contiguous, coalesced store.  The next window stages into the other buffer; the barrier of the window
     // after that orders this buffer's reuse behind these reads.
     const uint32_t wend = (uint32_t)k * g.ncb + ncbk < nbins ? off_k[ncbk] : s_total;
-#ifdef MSMZ_EXP_COARSE_NOWRITE
-    if (g.n == 0xffffffffu)
-#endif
     for (uint32_t p = threadIdx.x; p < wend - wbase; p += COARSE_T) packed_out[s_dst[buf][p]] = s_stage[buf][p];
   }
 }
@@ -322,8 +315,7 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
 // `n_half` / `endo_delta`: with GLV the entry index i >= n_half is the endomorphism half of point i - n_half; its
 // record sits at index i + endo_delta of the point set (the images follow the whole set, which may be larger than
 // the prefix this MSM covers: msm-batched-affine.ts:74-97 takes any N <= allocated).
-template <bool STAGE>
-__global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
+static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
                                                  const uint32_t* packed, const uint32_t* bin_base, int fb,
                                                  uint32_t n_bins, int idx_bits, uint32_t n_half, uint32_t endo_delta) {
   extern __shared__ uint32_t s_dyn[];
@@ -338,15 +330,6 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
   const uint32_t cnt_bin = end - begin;
   const bool staged = cnt_bin <= (uint32_t)FINE_STAGE;   // the bin fits the threads' registers (and the LDS staging)
   const uint32_t imask = (1u << idx_bits) - 1u;
-#ifdef MSMZ_EXP_STAMPS
-  uint64_t ts[8];
-  int nts = 0;
-  const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
-#define MSMZ_STAMP() ts[nts++] = __builtin_amdgcn_s_memtime()
-#else
-#define MSMZ_STAMP() (void)0
-#endif
-  MSMZ_STAMP();
   for (uint32_t f = threadIdx.x; f < nfine; f += FINE_T) s_cnt[f] = 0;
   // the bin's entries: all loads of a thread are issued back to back (the bin is read ONCE)
   uint32_t v[FINE_PER];
@@ -358,7 +341,6 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
     }
   }
   __syncthreads();
-  MSMZ_STAMP();   // 1: loads issued + zeroing + barrier
   // histogram; on the staged path the atomic's return value IS the entry's rank inside its bucket (kept in a register),
   // so no second round of atomics is needed: position = bucket offset + rank
   uint32_t rank[FINE_PER];
@@ -372,7 +354,6 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
     for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
   }
   __syncthreads();
-  MSMZ_STAMP();   // 2: loads arrived + rank atomics
   uint32_t mine = 0, mx = 0, cnts[2] = {0, 0};
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t f = threadIdx.x * per + j;
@@ -420,7 +401,6 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
   }
   if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
   __syncthreads();
-  MSMZ_STAMP();   // 3: scan + off stores
   auto to_ref = [&](uint32_t pv) {
     uint32_t idx = pv & imask;
     if (idx >= n_half) idx += endo_delta;   // endomorphism half: record index in the point set
@@ -431,25 +411,11 @@ __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, 
     for (int j = 0; j < FINE_PER; j++) {
       if ((uint32_t)j * FINE_T + threadIdx.x < cnt_bin) {
         const uint32_t pos = s_cnt[v[j] >> (idx_bits + 1)] + rank[j];
-        if (STAGE) s_stage[pos] = to_ref(v[j]); else refs[begin + pos] = to_ref(v[j]);
+        s_stage[pos] = to_ref(v[j]);
       }
     }
-    if (STAGE) {
-      __syncthreads();
-      MSMZ_STAMP();   // 4: placement in LDS
-      for (uint32_t p = threadIdx.x; p < cnt_bin; p += FINE_T) refs[begin + p] = s_stage[p];
-      MSMZ_STAMP();   // 5: copy-out issued
-#ifdef MSMZ_EXP_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)");
-      MSMZ_STAMP();   // 6: stores drained
-      if (threadIdx.x == 0)
-        printf("WG %u rt0 %llu rt1 %llu\n", bin, (unsigned long long)rt0, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-      if (threadIdx.x == 0 && (bin == 0 || bin == 300))
-        printf("k_fine bin %u cnt %u: load+zero %llu  hist %llu  scan %llu  place %llu  copy-issue %llu  drain %llu  (cycles)\n", bin, cnt_bin,
-               (unsigned long long)(ts[1] - ts[0]), (unsigned long long)(ts[2] - ts[1]), (unsigned long long)(ts[3] - ts[2]),
-               (unsigned long long)(ts[4] - ts[3]), (unsigned long long)(ts[5] - ts[4]), (unsigned long long)(ts[6] - ts[5]));
-#endif
-    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < cnt_bin; p += FINE_T) refs[begin + p] = s_stage[p];
   } else {
     // a bin too large for the LDS staging (heavily repeated scalars): second read, scattered stores
     for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) {
