@@ -34,7 +34,8 @@ enum {
 enum {
   MSMZ_TP_ADD = 0,     /* accumulator + accumulator (XYZZ add / extended twisted-Edwards add), all edge cases */
   MSMZ_TP_ADD_X4 = 1,  /* the 4-lane form used by the upper reduction levels                                 */
-  MSMZ_TP_DBL = 3      /* doubling of the first operand                                                      */
+  MSMZ_TP_DBL = 3,     /* doubling of the first operand                                                      */
+  MSMZ_TP_DBL_X4 = 4   /* 2 (a + b): 4-lane addition, then the 4-lane doubling of that (general) accumulator  */
 };
 
 /* out[i] = op(a[i], b[i]) for i < n; a, b, out: n * fe_bytes */

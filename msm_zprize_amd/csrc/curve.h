@@ -35,8 +35,15 @@ MSMZ_HD bool fe_reduced_is_zero(const Fe<F>& r) {
 }
 
 // lazy value (|v| < 2^4 p) == 0 mod p ?
+// Quick exact filter first: v = 0 mod p with |v| < 16 p means v = k p, |k| <= 15, and p = 1 mod 2^W, so the low W bits
+// of v (= of limb 0: lazy limbs carry nothing INTO limb 0) are k mod 2^W.  Anything else is non-zero -- which is every
+// value but ~2^-23 of them, so the full reduction below practically never runs.
 template <class F>
 MSMZ_HD bool fe_is_zero(const Fe<F>& a) {
+  if constexpr (F::PL[0] == 1) {
+    constexpr uint32_t MASK = (1u << F::W) - 1u;
+    if ((((uint32_t)a.l[0] + 15u) & MASK) > 30u) return false;
+  }
   Fe<F> t = a;
   fe_reduce_small(t);
   return fe_reduced_is_zero(t);

@@ -517,7 +517,7 @@ class Engine : public IEngine {
       MSMZ_HIP(hipMemcpyAsync(d_bi, b_inf, n, hipMemcpyHostToDevice, stream_));
     }
     using P = typename std::conditional<TE, TePolicy<F>, WeierPolicy<F>>::type;
-    const uint64_t threads = op == TP_ADD_X4 ? 4 * n : n;
+    const uint64_t threads = (op == TP_ADD_X4 || op == TP_DBL_X4) ? 4 * n : n;
     hipLaunchKernelGGL((k_test_point<P, TE>), dim3((threads + 63) / 64), dim3(64), 0, stream_, (uint32_t*)d_out,
                        (const uint32_t*)d_in, (const uint32_t*)(d_in + pb), d_ai, d_bi, (uint32_t)n, op);
     MSMZ_HIP(hipGetLastError());
@@ -797,7 +797,7 @@ class Engine : public IEngine {
   int reduce_levels(const Plan& pl, int& cur, uint32_t n_in) {
     constexpr int AW = P::ACC_WORDS;
     int st;
-    while (n_in > REDUCE_TAIL_N) {
+    while (n_in > tail_n_) {
       const uint32_t S = 4;   // quads handle short tails too
       uint32_t g2 = (n_in + S - 1) / S;
       int nxt = cur ^ 1;
@@ -1286,6 +1286,7 @@ class Engine : public IEngine {
   int chunk_shift_override_ = env_int("MSMZ_CHUNK_SHIFT", 0);
   int fb_cap_ = env_int("MSMZ_FB", 0);
   uint32_t s1_override_ = (uint32_t)env_int("MSMZ_S1", 0);
+  uint32_t tail_n_ = (uint32_t)env_int("MSMZ_TAIL_N", REDUCE_TAIL_N);   // entries per window at which k_reduce_tail takes over
   uint32_t quad16_max_groups_ = (uint32_t)env_int("MSMZ_QUAD16", 8192);   // levels with at most this many groups use k_reduce_quad16
   Host64<F> host64_;
   bool no_spread_ = env_int("MSMZ_NO_SPREAD", 0) != 0;

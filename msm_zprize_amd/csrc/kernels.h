@@ -782,9 +782,24 @@ __device__ __forceinline__ void fe_quad_bcast(Fe<F>& r, const Fe<F>& a) {   // r
 }
 
 template <class F>
-__device__ __forceinline__ void xyzz_add_x4(Xyzz<F>& r, const Xyzz<F>& p, const Xyzz<F>& q, int s) {
+__device__ __forceinline__ void fe_pick(Fe<F>& r, bool c, const Fe<F>& a, const Fe<F>& b) {   // r = c ? a : b
+#pragma unroll
+  for (int j = 0; j < F::N; j++) r.l[j] = c ? a.l[j] : b.l[j];
+}
+
+// r = p + q, or (dbl, uniform over the quad, q == p) r = 2p, in four product levels of <= 4 independent products:
+//   level   addition (add-2008-s)                         doubling (dbl-2008-s-1, a = 0)
+//     1     U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1      -
+//     2     PP = P^2, RR = R^2, ZZ1 ZZ2, ZZZ1 ZZZ2       V = U^2, XX = X^2            (U = 2Y, M = 3 XX)
+//     3     PPP = P PP, Q = U1 PP, ZZ3 = (ZZ1 ZZ2) PP    W = U V, S = X V, M^2, ZZ3 = ZZ V
+//     4     R (Q - X3), S1 PPP, ZZZ3 = (ZZZ1 ZZZ2) PPP   M (S - X3), Y W, ZZZ3 = ZZZ W
+// The reduction levels double on purpose (2a, 2 row, 4 row); as the equal-operands edge case of the addition those
+// doublings ran the sequential 9-product xyzz_dbl for the whole wave in three of the four steps of a level.
+template <class F>
+__device__ __forceinline__ void xyzz_add_x4(Xyzz<F>& r, const Xyzz<F>& p, const Xyzz<F>& q, int s, bool dbl) {
   const bool pinf = xyzz_is_inf(p), qinf = xyzz_is_inf(q);
-  Fe<F> a, b, m, U1, U2, S1, S2, P, R, PP, RR, Zm, Zc, PPP, Q, t, u;
+  Fe<F> a, b, m, U1, U2, S1, S2, P, R, PP, RR, Zm, Zc, PPP, Q, t, u, U, M, zero;
+  fe_zero(zero);
   fe_sel4(a, s, p.X, q.X, p.Y, q.Y);
   fe_sel4(b, s, q.ZZ, p.ZZ, q.ZZZ, p.ZZZ);
   fe_mul(m, a, b);
@@ -794,26 +809,46 @@ __device__ __forceinline__ void xyzz_add_x4(Xyzz<F>& r, const Xyzz<F>& p, const 
   fe_quad_bcast<3>(S2, m);
   fe_sub(P, U2, U1);
   fe_sub(R, S2, S1);
+  fe_add(U, p.Y, p.Y);
+  fe_carry(U);
+  // level 2
   fe_sel4(a, s, P, R, p.ZZ, p.ZZZ);
   fe_sel4(b, s, P, R, q.ZZ, q.ZZZ);
+  fe_pick(t, (s & 1) != 0, p.X, U);
+  fe_pick(a, dbl, t, a);
+  fe_pick(b, dbl, t, b);
   fe_mul(m, a, b);
-  fe_quad_bcast<0>(PP, m);
-  fe_quad_bcast<1>(RR, m);
+  fe_quad_bcast<0>(PP, m);    // doubling: V
+  fe_quad_bcast<1>(RR, m);    // doubling: XX
   fe_quad_bcast<2>(Zm, m);
   fe_quad_bcast<3>(Zc, m);
+  fe_add(M, RR, RR);
+  fe_add(M, M, RR);
+  fe_carry(M);
+  // level 3
   fe_sel4(a, s, P, U1, Zm, Zm);
-  fe_mul(m, a, PP);
-  fe_quad_bcast<0>(PPP, m);
-  fe_quad_bcast<1>(Q, m);
-  fe_quad_bcast<2>(r.ZZ, m);
-  fe_sub(t, RR, PPP);
+  fe_sel4(t, s, U, p.X, M, p.ZZ);
+  fe_pick(a, dbl, t, a);
+  fe_pick(b, dbl && s == 2, M, PP);
+  fe_mul(m, a, b);
+  fe_quad_bcast<0>(PPP, m);   // doubling: W
+  fe_quad_bcast<1>(Q, m);     // doubling: S
+  fe_quad_bcast<2>(t, m);     // addition: ZZ3; doubling: M^2
+  fe_quad_bcast<3>(u, m);     // doubling: ZZ3
+  fe_pick(r.ZZ, dbl, u, t);
+  fe_pick(RR, dbl, t, RR);
+  fe_pick(u, dbl, zero, PPP);
+  fe_sub(t, RR, u);
   fe_sub(t, t, Q);
   fe_sub(u, t, Q);       // X3
   fe_carry(u);
   fe_sub(t, Q, u);
   fe_carry(t);
+  // level 4
   fe_sel4(a, s, R, S1, Zc, Zc);
-  fe_sel4(b, s, t, PPP, PPP, PPP);
+  fe_sel4(m, s, M, p.Y, p.ZZZ, p.ZZZ);
+  fe_pick(a, dbl, m, a);
+  fe_pick(b, s == 0, t, PPP);
   fe_mul(m, a, b);
   fe_quad_bcast<0>(Q, m);
   fe_quad_bcast<1>(t, m);
@@ -821,18 +856,18 @@ __device__ __forceinline__ void xyzz_add_x4(Xyzz<F>& r, const Xyzz<F>& p, const 
   fe_sub(r.Y, Q, t);
   fe_carry(r.Y);
   r.X = u;
-  // edge cases exactly as xyzz_add (uniform over the quad: all four lanes hold the same operands)
+  // edge cases exactly as xyzz_add / xyzz_dbl (uniform over the quad: all four lanes hold the same operands)
   if (pinf) {
     r = q;
   } else if (qinf) {
     r = p;
-  } else if (fe_is_zero(P)) {
+  } else if (!dbl && fe_is_zero(P)) {
     if (fe_is_zero(R)) xyzz_dbl(r, p); else xyzz_set_inf(r);
   }
 }
 
 template <class F>
-__device__ __forceinline__ void te_add_x4(TeExt<F>& r, const TeExt<F>& p, const TeExt<F>& q, int s) {
+__device__ __forceinline__ void te_add_x4(TeExt<F>& r, const TeExt<F>& p, const TeExt<F>& q, int s, bool) {   // the unified addition doubles as well
   Fe<F> a, b, m, A, B, C, D, E, Fv, G, H, t, u, v, w, k;
   fe_sub(t, p.Y, p.X);
   fe_sub(u, q.Y, q.X);
@@ -883,7 +918,7 @@ struct WeierPolicy {
   static __device__ __forceinline__ void zero(Acc& a) { xyzz_set_inf(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { xyzz_add(r, a, b); }
   static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { xyzz_dbl(r, a); }
-  static __device__ __forceinline__ void add_x4(Acc& r, const Acc& a, const Acc& b, int s) { xyzz_add_x4(r, a, b, s); }
+  static __device__ __forceinline__ void add_x4(Acc& r, const Acc& a, const Acc& b, int s, bool dbl) { xyzz_add_x4(r, a, b, s, dbl); }
   static __device__ __forceinline__ void madd(Acc& r, const Acc& a, const uint32_t* rec, uint32_t neg) {
     Affine<F> p;
     bool inf = load_affine<F>(p, rec, neg);
@@ -913,7 +948,7 @@ struct TePolicy {
   static __device__ __forceinline__ void zero(Acc& a) { te_set_zero(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { te_add(r, a, b); }
   static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { te_add(r, a, a); }
-  static __device__ __forceinline__ void add_x4(Acc& r, const Acc& a, const Acc& b, int s) { te_add_x4(r, a, b, s); }
+  static __device__ __forceinline__ void add_x4(Acc& r, const Acc& a, const Acc& b, int s, bool dbl) { te_add_x4(r, a, b, s, dbl); }
   static __device__ __forceinline__ void madd(Acc& r, const Acc& a, const uint32_t* rec, uint32_t neg) {
     TeNiels<F> n;
     Fe<F> pad;
@@ -1174,7 +1209,7 @@ __device__ __forceinline__ void reduce_group16(uint32_t* rows_out, uint32_t* c_o
   {
     const int src[4] = {1, 3, 3, 2};
     quad_fetch<P>(got, q == 2 ? c : r, base_lane + 4 * src[q]);
-    P::add_x4(v, q == 3 ? c : r, got, s);   // L0 s01, L1 b, L2 a, L3 c23
+    P::add_x4(v, q == 3 ? c : r, got, s, false);   // L0 s01, L1 b, L2 a, L3 c23
   }
   {
     const int src[4] = {2, 0, 2, 3};
@@ -1182,24 +1217,27 @@ __device__ __forceinline__ void reduce_group16(uint32_t* rows_out, uint32_t* c_o
     if (q == 3) P::zero(got);
     Acc lhs = (q == 1) ? c : v;
     if (q == 3) P::zero(lhs);
-    P::add_x4(w, lhs, got, s);              // L0 row, L1 c01, L2 2a, L3 0
+    P::add_x4(w, lhs, got, s, q == 2);      // L0 row, L1 c01, L2 2a, L3 0
   }
   {
     const int src[4] = {0, 3, 1, 3};
     quad_fetch<P>(got, q == 0 ? w : v, base_lane + 4 * src[q]);
-    P::add_x4(r, w, got, s);                // L0 2 row, L1 cs, L2 tri
+    P::add_x4(r, w, got, s, q == 0);        // L0 2 row, L1 cs, L2 tri
   }
   {
     const int src[4] = {0, 2, 2, 3};
     quad_fetch<P>(got, r, base_lane + 4 * src[q]);
-    P::add_x4(c, r, got, s);                // L0 4 row, L1 C' = cs + tri
+    P::add_x4(c, r, got, s, q == 0);        // L0 4 row, L1 C' = cs + tri
   }
   if (live && q == 0 && s == 0) P::store(rows_out + (size_t)A * XW, c);
   if (live && q == 1 && s == 0) P::store(c_out + (size_t)A * XW, c);
 }
 
+#ifndef MSMZ_Q16_OCC
+#define MSMZ_Q16_OCC 1
+#endif
 template <class P>
-__global__ void __launch_bounds__(64, 1) k_reduce_quad16(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
+__global__ void __launch_bounds__(64, MSMZ_Q16_OCC) k_reduce_quad16(uint32_t* rows_out, uint32_t* c_out, const uint32_t* rows_in,
                                                          const uint32_t* c_in, uint32_t n_in, uint32_t groups,
                                                          uint32_t total) {
   constexpr int XW = P::ACC_WORDS;
@@ -1218,7 +1256,7 @@ __global__ void __launch_bounds__(64, 1) k_reduce_quad16(uint32_t* rows_out, uin
 // the four levels below 128 entries cost ~85 us each, together ~4 x 35 us).  The window's rows/c ping-pong between
 // (r0, c0) and (r1, c1), n_in entries apart per window; the final C (the window sum) is written to c_final[k].
 constexpr int REDUCE_TAIL_T = 256;   // one wave per SIMD: the 4-lane additions need ~370 VGPRs (at 256 they spill to scratch)
-constexpr uint32_t REDUCE_TAIL_N = 128;   // entries per window at which the tail kernel takes over
+constexpr uint32_t REDUCE_TAIL_N = 32;    // entries per window at which the tail kernel takes over (16 groups = one pass of the workgroup; measured 128: 1.355, 64: 1.324, 32: 1.308, 16: 1.333 ms of reduce)
 template <class P>
 __global__ void __launch_bounds__(REDUCE_TAIL_T, 1) k_reduce_tail(uint32_t* r0, uint32_t* c0, uint32_t* r1, uint32_t* c1,
                                                                   uint32_t* c_final, uint32_t n_in, uint32_t stride) {

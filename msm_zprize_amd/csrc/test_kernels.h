@@ -14,7 +14,7 @@ enum {   // field ops (msmz_test_field)
   TF_IS_ZERO = 7, TF_SLOT_ROUNDTRIP = 8
 };
 enum {   // point ops (msmz_test_point)
-  TP_ADD = 0, TP_ADD_X4 = 1, TP_MADD = 2, TP_DBL = 3
+  TP_ADD = 0, TP_ADD_X4 = 1, TP_MADD = 2, TP_DBL = 3, TP_DBL_X4 = 4
 };
 
 // Operands / results are NW memory words per element (little endian).  Inputs are lazy Montgomery residues: any
@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(64) k_test_point(uint32_t* out, const uint32_t
   using Acc = typename P::Acc;
   constexpr int NW = F::NW;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t i = op == TP_ADD_X4 ? t >> 2 : t;   // a DPP quad per pair for the 4-lane addition
+  const bool x4 = op == TP_ADD_X4 || op == TP_DBL_X4;
+  const uint32_t i = x4 ? t >> 2 : t;   // a DPP quad per pair for the 4-lane addition
   const uint32_t ii = i < n ? i : n - 1;
   auto load = [&](Acc& p, const uint32_t* in, const uint8_t* inf) {
     Fe<F> x, y, xm, ym;
@@ -163,11 +164,17 @@ __global__ void __launch_bounds__(64) k_test_point(uint32_t* out, const uint32_t
   load(b, b_in, b_inf);
   switch (op) {
     case TP_ADD: P::add(r, a, b); break;
-    case TP_ADD_X4: P::add_x4(r, a, b, (int)(threadIdx.x & 3)); break;
+    case TP_ADD_X4: P::add_x4(r, a, b, (int)(threadIdx.x & 3), false); break;
+    case TP_DBL_X4: {   // 2 (a + b): the doubling on a general accumulator (ZZ != 1)
+      Acc sum;
+      P::add_x4(sum, a, b, (int)(threadIdx.x & 3), false);
+      P::add_x4(r, sum, sum, (int)(threadIdx.x & 3), true);
+      break;
+    }
     case TP_DBL: P::dbl(r, a); break;
     default: P::add(r, a, b); break;
   }
-  if (i >= n || (op == TP_ADD_X4 && (threadIdx.x & 3) != 0)) return;
+  if (i >= n || (x4 && (threadIdx.x & 3) != 0)) return;
   uint32_t w[2 * NW];
   if constexpr (TE) {
     te_to_affine_canon<F>(w, r);

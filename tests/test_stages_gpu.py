@@ -17,7 +17,7 @@ CURVES = ["bls12-377", "pallas", "bls12-381", "ed-on-bls12-377"]
 # Montgomery radix of the device representation: N limbs of W bits (csrc/constants_gen.h)
 RADIX_BITS = {"bls12-377": 14 * 28, "bls12-381": 14 * 28, "pallas": 9 * 29, "ed-on-bls12-377": 9 * 29}
 (TF_MUL, TF_SQR, TF_ADD, TF_SUB, TF_INVERSE, TF_INVERSE_WAVE, TF_ROUNDTRIP, TF_IS_ZERO, TF_SLOT_ROUNDTRIP) = range(9)
-TP_ADD, TP_ADD_X4, TP_DBL = 0, 1, 3
+TP_ADD, TP_ADD_X4, TP_DBL, TP_DBL_X4 = 0, 1, 3, 4
 
 
 @pytest.fixture(scope="module")
@@ -261,6 +261,7 @@ def test_xyzz_point_arithmetic(ctxs, label):
     assert run(TP_ADD) == want_add
     assert run(TP_ADD_X4) == want_add
     assert run(TP_DBL) == [norm(A.double(x)) for x in ops_a]
+    assert run(TP_DBL_X4) == [norm(A.double(w)) for w in want_add]
 
 
 def test_twisted_edwards_point_arithmetic(ctxs):
@@ -289,3 +290,4 @@ def test_twisted_edwards_point_arithmetic(ctxs):
     assert run(TP_ADD) == want
     assert run(TP_ADD_X4) == want
     assert run(TP_DBL) == [aff(T.double(T.from_affine(x))) for x in a]
+    assert run(TP_DBL_X4) == [aff(T.double(T.add(T.from_affine(x), T.from_affine(y)))) for x, y in zip(a, b)]
