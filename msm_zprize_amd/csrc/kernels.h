@@ -1252,11 +1252,13 @@ __global__ void __launch_bounds__(64, MSMZ_Q16_OCC) k_reduce_quad16(uint32_t* ro
 }
 
 // The LAST levels in one launch: one workgroup per window walks n_in -> ceil(n_in/4) -> ... -> 1 with a barrier
-// between levels (each level is 4 x 4 dependent field products of latency, whatever its size: as separate launches
-// the four levels below 128 entries cost ~85 us each, together ~4 x 35 us).  The window's rows/c ping-pong between
+// between levels (each level is 4 x 4 dependent field products of latency, ~47 us, whatever its size; one launch
+// saves the kernel boundaries, not the products).  The window's rows/c ping-pong between
 // (r0, c0) and (r1, c1), n_in entries apart per window; the final C (the window sum) is written to c_final[k].
 constexpr int REDUCE_TAIL_T = 256;   // one wave per SIMD: the 4-lane additions need ~370 VGPRs (at 256 they spill to scratch)
-constexpr uint32_t REDUCE_TAIL_N = 32;    // entries per window at which the tail kernel takes over (16 groups = one pass of the workgroup; measured 128: 1.355, 64: 1.324, 32: 1.308, 16: 1.333 ms of reduce)
+// entries per window at which the tail kernel takes over: its first level is then 8 groups = one pass of the
+// workgroup (reduce stage at 2^20 with 128 / 64 / 32 / 16: 1.355 / 1.324 / 1.308 / 1.333 ms)
+constexpr uint32_t REDUCE_TAIL_N = 32;
 template <class P>
 __global__ void __launch_bounds__(REDUCE_TAIL_T, 1) k_reduce_tail(uint32_t* r0, uint32_t* c0, uint32_t* r1, uint32_t* c1,
                                                                   uint32_t* c_final, uint32_t n_in, uint32_t stride) {
