@@ -5,10 +5,10 @@
 // chunk-interleaved result array (kernels.h).  Round 0 gathers the original points.
 //
 // Batch inversion (Montgomery's trick) on two levels:
-//   * each thread walks B pairs like batchAddUnsafeNew (curve-affine.ts:463-522): the forward pass keeps a running
-//     product of the denominators and parks  z_i = numerator_i * prod_{j<i} d_j  in the pair's output record; the
-//     backward pass reads the descriptor again, reloads x1, (x2, y2) and z_i and turns z_i into the slope with the
-//     running inverse;
+//   * each thread walks B pairs like batchAddUnsafeNew (curve-affine.ts:463-522): the forward pass reads only the x
+//     coordinates, keeps a running product of the denominators and parks  z_i = prod_{j<i} d_j  in the pair's output
+//     record; the backward pass reads the descriptor again, reloads both points and z_i, and  z_i * (running inverse)
+//     is 1 / d_i;
 //   * the T per-thread products of a workgroup are inverted together: product tree in LDS, ONE field
 //     inversion (wave 0, fe_inverse_wave), down-sweep.
 // 6 field products per addition + (3 T + inversion) per workgroup of T*B additions.
@@ -60,14 +60,16 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       dd.x = LOC_ORIG | (t & 4095u);
       dd.y = LOC_ORIG | ((t + 1u) & 4095u);
 #endif
-      Affine<F> p1, p2;
-      const bool infA = load_operand<F, SAFE>(p1, dd.x, slots, points);
-      const bool infB = load_operand<F, SAFE>(p2, dd.y, slots, points);
-      Fe<F> d, num;
-      fe_sub(d, p2.x, p1.x);
-      fe_sub(num, p2.y, p1.y);
+      // the unsafe path only needs the denominators here: x coordinates (the numerator joins in the backward pass)
+      Fe<F> d;
       kind = PK_ADD;
-      if (SAFE) {
+      if constexpr (SAFE) {
+        Affine<F> p1, p2;
+        const bool infA = load_operand<F, true>(p1, dd.x, slots, points);
+        const bool infB = load_operand<F, true>(p2, dd.y, slots, points);
+        Fe<F> num;
+        fe_sub(d, p2.x, p1.x);
+        fe_sub(num, p2.y, p1.y);
         if (infA) {
           kind = infB ? PK_INF : PK_TAKE_B;
         } else if (infB) {
@@ -76,24 +78,23 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
           if (fe_is_zero(num) && !fe_is_zero(p1.y)) {
             kind = PK_DBL;
             fe_add(d, p2.y, p2.y);          // 2y
-            Fe<F> xx;
-            fe_sqr(xx, p2.x);
-            fe_add(num, xx, xx);
-            fe_add(num, num, xx);           // 3x^2
-            fe_carry(num);
           } else {
             kind = PK_INF;
           }
         }
+      } else {
+        Fe<F> x1, x2;
+        load_operand_x<F>(x1, dd.x, slots, points);
+        load_operand_x<F>(x2, dd.y, slots, points);
+        fe_sub(d, x2, x1);
       }
       if (kind == PK_ADD || kind == PK_DBL) {
-        // park z = prefix * numerator in the pair's output record (a product's limbs are valid inputs as they are)
-        Fe<F> z;
-        BM_MUL(z, prefix, num);
+        // park the running product of the denominators BEFORE this pair in the pair's output record
+        // (a product's limbs are valid inputs as they are)
 #if defined(MSMZ_EXP_LOCALMEM) || defined(MSMZ_EXP_LOCAL_Z)
-        slot_store_mulout<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), z);
+        slot_store_mulout<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), prefix);
 #else
-        slot_store_mulout<F>(slots + slot_offset<F>(out_base + t), z);
+        slot_store_mulout<F>(slots + slot_offset<F>(out_base + t), prefix);
 #endif
         Fe<F> np;
         BM_MUL(np, prefix, d);
@@ -207,18 +208,25 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     if (kind == PK_ADD || kind == PK_DBL) {
       Affine<F> p2;
       load_operand<F, false>(p2, dd.y, slots, points);
-      Fe<F> z, mm, ms, d, tt, s12;
-      slot_load_fe<F>(z, out);              // parked by the forward pass
+      Fe<F> z, mm, ms, d, tt, s12, num;
+      slot_load_fe<F>(z, out);              // parked by the forward pass: product of the denominators before this pair
       if (kind == PK_ADD) {
-        Fe<F> x1;
-        load_operand_x<F>(x1, dd.x, slots, points);
-        fe_sub(d, p2.x, x1);
-        fe_add(s12, p2.x, x1);
+        Affine<F> p1;
+        load_operand<F, false>(p1, dd.x, slots, points);
+        fe_sub(d, p2.x, p1.x);
+        fe_sub(num, p2.y, p1.y);
+        fe_add(s12, p2.x, p1.x);
       } else {
         fe_add(d, p2.y, p2.y);
         fe_add(s12, p2.x, p2.x);
+        Fe<F> xx;
+        fe_sqr(xx, p2.x);
+        fe_add(num, xx, xx);
+        fe_add(num, num, xx);               // 3x^2
+        fe_carry(num);
       }
-      BM_MUL(mm, z, run);                 // slope
+      BM_MUL(tt, z, run);                 // 1 / denominator of this pair
+      BM_MUL(mm, num, tt);                // slope
       BM_MUL(tt, run, d);
       run = tt;
       BM_SQR(ms, mm);
