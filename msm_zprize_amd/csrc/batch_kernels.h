@@ -91,10 +91,11 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       if (kind == PK_ADD || kind == PK_DBL) {
         // park the running product of the denominators BEFORE this pair in the pair's output record
         // (a product's limbs are valid inputs as they are)
+        // (the first pair's is the constant one: not stored)
 #if defined(MSMZ_EXP_LOCALMEM) || defined(MSMZ_EXP_LOCAL_Z)
-        slot_store_mulout<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), prefix);
+        if (i > 0) slot_store_mulout<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), prefix);
 #else
-        slot_store_mulout<F>(slots + slot_offset<F>(out_base + t), prefix);
+        if (i > 0) slot_store_mulout<F>(slots + slot_offset<F>(out_base + t), prefix);
 #endif
         Fe<F> np;
         BM_MUL(np, prefix, d);
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       Affine<F> p2;
       load_operand<F, false>(p2, dd.y, slots, points);
       Fe<F> z, mm, ms, d, tt, s12, num;
-      slot_load_fe<F>(z, out);              // parked by the forward pass: product of the denominators before this pair
+      if (i > 0) slot_load_fe<F>(z, out); else fe_set_const<F>(z, F::ONE);   // parked by the forward pass: product of the denominators before this pair
       if (kind == PK_ADD) {
         Affine<F> p1;
         load_operand<F, false>(p1, dd.x, slots, points);
