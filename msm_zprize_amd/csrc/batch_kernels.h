@@ -63,7 +63,33 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       // the unsafe path only needs the denominators here: x coordinates (the numerator joins in the backward pass)
       Fe<F> d;
       kind = PK_ADD;
-      if constexpr (SAFE) {
+      if constexpr (SAFE && SlotFmt<F>::PACKED) {
+        // x coordinates first; the y coordinates are fetched only where an edge case is possible: a zero x (the
+        // record may be the all-zero infinity record) or equal x (doubling / opposite points)
+        Fe<F> x1, x2;
+        const uint32_t oa = load_operand_x_or<F>(x1, dd.x, slots, points);
+        const uint32_t ob = load_operand_x_or<F>(x2, dd.y, slots, points);
+        fe_sub(d, x2, x1);
+        if (oa == 0 || ob == 0 || fe_is_zero(d)) {
+          Affine<F> p1, p2;
+          const bool infA = load_operand<F, true>(p1, dd.x, slots, points);
+          const bool infB = load_operand<F, true>(p2, dd.y, slots, points);
+          if (infA) {
+            kind = infB ? PK_INF : PK_TAKE_B;
+          } else if (infB) {
+            kind = PK_TAKE_A;
+          } else if (fe_is_zero(d)) {
+            Fe<F> num;
+            fe_sub(num, p2.y, p1.y);
+            if (fe_is_zero(num) && !fe_is_zero(p1.y)) {
+              kind = PK_DBL;
+              fe_add(d, p2.y, p2.y);          // 2y
+            } else {
+              kind = PK_INF;
+            }
+          }
+        }
+      } else if constexpr (SAFE) {
         Affine<F> p1, p2;
         const bool infA = load_operand<F, true>(p1, dd.x, slots, points);
         const bool infB = load_operand<F, true>(p2, dd.y, slots, points);

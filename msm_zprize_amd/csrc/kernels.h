@@ -576,6 +576,29 @@ __device__ __forceinline__ bool load_operand(Affine<F>& p, uint32_t loc, const u
     return slot_load_point<F, CHECK_INF>(p, slots + slot_offset<F>(loc));
   }
 }
+// x coordinate only, packed records; returns the OR of its words (zero: the record may be the all-zero infinity record)
+template <class F>
+__device__ __forceinline__ uint32_t load_operand_x_or(Fe<F>& x, uint32_t loc, const uint32_t* slots,
+                                                      const uint32_t* points) {
+  static_assert(SlotFmt<F>::PACKED, "packed slot records");
+  int cs;
+  uint32_t neg;
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(operand_address<F>(loc, slots, points, cs, neg));
+  uint32_t w[F::NW];
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < F::NW / 4; i++) {
+    const u32x4 v = s4[i * cs];
+    w[4 * i] = v.x;
+    w[4 * i + 1] = v.y;
+    w[4 * i + 2] = v.z;
+    w[4 * i + 3] = v.w;
+    o |= v.x | v.y | v.z | v.w;
+  }
+  fe_unpack<F>(x, w);
+  return o;
+}
+
 // x coordinate only
 template <class F>
 __device__ __forceinline__ void load_operand_x(Fe<F>& x, uint32_t loc, const uint32_t* slots, const uint32_t* points) {
