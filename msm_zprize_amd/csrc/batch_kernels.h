@@ -39,12 +39,19 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   // product tree over the T per-thread products.  Level 1 (pairs of neighbouring lanes) is formed with
   // a lane shuffle, levels 1..log2(T) live in LDS limb-major: level d at offset T - (T >> (d-1)), T-1 nodes.
   __shared__ int32_t tree[F::N * T];
+  __shared__ int32_t s_prev[F::N * T];   // limb-major: the prefix product before each thread's LAST pair (not parked in HBM)
   __shared__ uint8_t s_kind[SAFE ? BMAX * T : 1];
   constexpr int N = F::N;
   const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
 
   Fe<F> prefix;
   fe_set_const<F>(prefix, F::ONE);
+  // index of the thread's last pair (pairs t = block_base + i*T + threadIdx.x < total)
+  int ilast = -1;
+  if (block_base + threadIdx.x < total) {
+    const uint32_t room = (total - 1u - block_base - threadIdx.x) / (uint32_t)T;
+    ilast = room < (uint32_t)(B - 1) ? (int)room : B - 1;
+  }
   // ---------------------------------------------------------------- forward pass
   // (the next pair's descriptor is requested one iteration ahead: operand addresses never wait for it)
   uint2 dnext = make_uint2(0, 0);
@@ -117,12 +124,17 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       if (kind == PK_ADD || kind == PK_DBL) {
         // park the running product of the denominators BEFORE this pair in the pair's output record
         // (a product's limbs are valid inputs as they are)
-        // (the first pair's is the constant one: not stored)
+        // (the first pair's is the constant one and the last pair's stays in LDS: neither goes to HBM)
+        if (i == ilast) {
+#pragma unroll
+          for (int j = 0; j < N; j++) s_prev[j * T + threadIdx.x] = prefix.l[j];
+        } else if (i > 0) {
 #if defined(MSMZ_EXP_LOCALMEM) || defined(MSMZ_EXP_LOCAL_Z)
-        if (i > 0) slot_store_mulout<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), prefix);
+          slot_store_mulout<F>(slots + slot_offset<F>(blockIdx.x * 64u + (t & 63u)), prefix);
 #else
-        if (i > 0) slot_store_mulout<F>(slots + slot_offset<F>(out_base + t), prefix);
+          slot_store_mulout<F>(slots + slot_offset<F>(out_base + t), prefix);
 #endif
+        }
         Fe<F> np;
         BM_MUL(np, prefix, d);
         prefix = np;
@@ -236,7 +248,16 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       Affine<F> p2;
       load_operand<F, false>(p2, dd.y, slots, points);
       Fe<F> z, mm, ms, d, tt, s12, num;
-      if (i > 0) slot_load_fe<F>(z, out); else fe_set_const<F>(z, F::ONE);   // parked by the forward pass: product of the denominators before this pair
+      // product of the denominators before this pair: parked by the forward pass, except the last pair's (LDS)
+      // and the first pair's (one)
+      if (i == ilast) {
+#pragma unroll
+        for (int j = 0; j < N; j++) z.l[j] = s_prev[j * T + threadIdx.x];
+      } else if (i > 0) {
+        slot_load_fe<F>(z, out);
+      } else {
+        fe_set_const<F>(z, F::ONE);
+      }
       if (kind == PK_ADD) {
         Affine<F> p1;
         load_operand<F, false>(p1, dd.x, slots, points);
