@@ -52,7 +52,8 @@ enum { MSMZ_BUCKETS_AFFINE = 0, MSMZ_BUCKETS_PROJECTIVE = 1 };
  * choices BASELINE.json's configs name (GLV on/off, affine vs projective buckets). 0 = default. */
 typedef struct msmz_opts {
   int32_t c;        /* window size in bits; 0 = pick from N like windowSizeAffine (msm-common.ts:15-21) */
-  int32_t glv;      /* 1 = GLV endomorphism split (reference default for Weierstrass), 0 = off */
+  int32_t glv;      /* 1 = GLV endomorphism split (the reference always splits on Weierstrass curves), 0 = off,
+                     * -1 = the engine picks (GLV below 2^21 points, the measured crossover; the result is the same) */
   int32_t safe;     /* 1 = msm (handles equal / opposite / infinity points), 0 = msmUnsafe */
   int32_t buckets;  /* MSMZ_BUCKETS_AFFINE (batched-affine) or MSMZ_BUCKETS_PROJECTIVE (msmProjective) */
   int32_t timing;   /* 1 = fill msmz_log stage timings with HIP events (the reference's tic/toc log) */

@@ -100,7 +100,7 @@ function createCurve(params, kind) {
     options = options || {};
     const opts = {
       c: options.c || 0,
-      glv: options.glv !== undefined ? Number(options.glv) : te ? 0 : 1,
+      glv: options.glv !== undefined ? Number(options.glv) : te ? 0 : -1,   // -1: GLV below 2^21 points (include/msmz.h)
       safe: options.useSafeAdditions !== undefined ? Number(options.useSafeAdditions) : safe,
       buckets,
       timing: verbose ? 1 : 0,

@@ -326,6 +326,9 @@ class Engine : public IEngine {
     msmz_opts opt;
     memset(&opt, 0, sizeof(opt));
     if (o) opt = *o;
+    // glv < 0: the engine's choice.  The split halves the windows but doubles the point set: ahead up to 2^20 points
+    // (4.0 vs 4.1 ms), behind from 2^21 on (7.1 vs 6.7 ms; 25.1 vs 22.3 ms at 2^23) -- profiles/r02_sweep.json.
+    if (opt.glv < 0) opt.glv = (!TE && Fr::HAS_GLV && pit->second.has_endo && n < (1ull << 21)) ? 1 : 0;
     MSMZ_HIP(hipSetDevice(device_));
 
     const uint32_t* d_scalars = nullptr;

@@ -218,7 +218,7 @@ class _Curve:
         self.params = params
         self.kind = kind
         self.fe_bytes = params["fe_bytes"]
-        self.default_glv = 1 if kind == "weierstrass" else 0
+        self.default_glv = -1 if kind == "weierstrass" else 0   # -1: GLV below 2^21 points (include/msmz.h)
         ctx = C.c_void_p()
         devs = _state["devices"]
         self.devices = list(devs)

@@ -64,6 +64,21 @@ def test_config2_bls12_377_2e20_no_glv_affine(mod):
     curve.close()
 
 
+def test_default_glv_choice_follows_the_input_size(mod):
+    """options without `glv`: the engine splits with GLV below 2^21 points and not from there on (include/msmz.h);
+    either way the result is the closed form"""
+    curve = mod.Weierstrass.create(mod.curves.bls12377Params)
+    for log2n, glv in ((12, 1), (21, 0)):
+        n = 1 << log2n
+        pts = curve.Parallel.randomPointsFast(n, 21)
+        sc = curve.Parallel.randomScalars(n, 22)
+        out = curve.Parallel.msmUnsafe(sc, pts, n, True)
+        assert out["result"] == _expected("bls12-377", 21, 22, n)
+        assert out["stats"].glv == glv
+        pts.free(); sc.free()
+    curve.close()
+
+
 def test_config3_pallas_2e22_projective(mod):
     """BASELINE configs[2]: Pallas 2^22, projective buckets (msmProjective, parallel.ts:69-87)"""
     curve = mod.Weierstrass.create(mod.curves.pallasParams)
