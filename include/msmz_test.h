@@ -38,6 +38,13 @@ enum {
   MSMZ_TP_DBL_X4 = 4   /* 2 (a + b): 4-lane addition, then the 4-lane doubling of that (general) accumulator  */
 };
 
+/* GLV half-scalar bound (src/wasm/glv.ts:216-226 `maxBits`).  The engine sizes the windows for halves below 2^127 and
+ * lets the slicing kernel flag a longer half, in which case the MSM is redone with windows for the analytic bound
+ * (GLV_PROVEN_BITS, tools/gen_constants.py).  No real scalar is known to take that path, so this hook shrinks the
+ * ASSUMED bit length (8 .. 127; 0 restores the default): ordinary halves then overflow, the flag is raised and the
+ * redone MSM must still equal the oracle.  msmz_test_retries = number of MSMs (per-engine passes) redone so far. */
+int msmz_test_set_glv_bits(msmz_ctx* ctx, int bits);
+int msmz_test_retries(msmz_ctx* ctx);
 /* out[i] = op(a[i], b[i]) for i < n; a, b, out: n * fe_bytes */
 int msmz_test_field(msmz_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out);
 /* GLV split of n 32-byte scalars: s0, s1 = magnitudes (16 bytes each), neg = 2 sign bytes per scalar

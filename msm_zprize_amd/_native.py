@@ -46,6 +46,8 @@ EXPORTS = {
                                     C.POINTER(C.c_int), C.POINTER(MsmzLog)]),
     "msmz_point_add": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
     # stage-level test hooks (include/msmz_test.h)
+    "msmz_test_set_glv_bits": (C.c_int, [C.c_void_p, C.c_int]),
+    "msmz_test_retries": (C.c_int, [C.c_void_p]),
     "msmz_test_field": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p]),
     "msmz_test_glv": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p]),
     "msmz_test_digits": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]),

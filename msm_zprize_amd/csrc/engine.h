@@ -27,7 +27,7 @@ namespace msmz {
   do {                                                                                     \
     hipError_t e_ = (x);                                                                   \
     if (e_ != hipSuccess) {                                                                \
-      fprintf(stderr, "msmz: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      fprintf(stderr, "msmz: HIP error '%s' from `%s` at %s:%d\n", hipGetErrorString(e_), #x, __FILE__, __LINE__); \
       return MSMZ_ERR_HIP;                                                                 \
     }                                                                                      \
   } while (0)
@@ -158,7 +158,42 @@ class Engine : public IEngine {
     for (auto& e : ev_) MSMZ_HIP(hipEventCreate(&e));
     MSMZ_HIP(hipHostMalloc(&h_meta_, sizeof(MsmMeta)));
     MSMZ_HIP(hipHostMalloc(&h_final_, (size_t)2 * kMaxWindows * XW * 4));
+    // Kernels that stage more than the default dynamic-LDS allowance get their limit raised ONCE, here, right after
+    // hipSetDevice -- not lazily inside the first MSM and not on every MSM.  static + dynamic LDS is checked against
+    // the device's per-workgroup LDS, so a kernel that cannot launch fails context creation with its name.
+    int st;
+    if ((st = raise_lds_limit((const void*)k_fine, "k_fine", kFineLds))) return st;
+    if ((st = raise_lds_limit((const void*)k_coarse<Fr, false>, "k_coarse", kCoarseLdsMax))) return st;
+    if ((st = raise_lds_limit((const void*)k_hist<Fr, false>, "k_hist", kHistLdsMax))) return st;
+    if constexpr (Fr::HAS_GLV) {
+      if ((st = raise_lds_limit((const void*)k_coarse<Fr, true>, "k_coarse<glv>", kCoarseLdsMax))) return st;
+      if ((st = raise_lds_limit((const void*)k_hist<Fr, true>, "k_hist<glv>", kHistLdsMax))) return st;
+    }
     return meta_.ensure(sizeof(MsmMeta));
+  }
+
+  // dynamic LDS the sort kernels may be launched with (sort_phase never asks for more: SORT_MAX_BINS caps nbins)
+  static constexpr size_t kFineLds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
+  static constexpr size_t kCoarseLdsMax = (size_t)3 * SORT_MAX_BINS * 4;
+  static constexpr size_t kHistLdsMax = (size_t)SORT_MAX_BINS * 4;
+
+  int raise_lds_limit(const void* fn, const char* name, size_t dyn_max) {
+    hipFuncAttributes fa;
+    memset(&fa, 0, sizeof(fa));
+    MSMZ_HIP(hipFuncGetAttributes(&fa, fn));
+    hipDeviceProp_t prop;
+    MSMZ_HIP(hipGetDeviceProperties(&prop, device_));
+    // per-workgroup LDS of the device: gfx950 reports 160 KiB as the opt-in maximum (64 KiB is the default allowance)
+    size_t dev_max = prop.sharedMemPerBlock;
+    if (prop.sharedMemPerBlockOptin > dev_max) dev_max = prop.sharedMemPerBlockOptin;
+    if (prop.maxSharedMemoryPerMultiProcessor > dev_max) dev_max = prop.maxSharedMemoryPerMultiProcessor;
+    if (fa.sharedSizeBytes + dyn_max > dev_max) {
+      fprintf(stderr, "msmz: %s needs %zu B static + %zu B dynamic LDS, the device offers %zu B per workgroup\n", name,
+              (size_t)fa.sharedSizeBytes, dyn_max, dev_max);
+      return MSMZ_ERR_HIP;
+    }
+    MSMZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+    return MSMZ_OK;
   }
 
   ~Engine() override {
@@ -175,16 +210,34 @@ class Engine : public IEngine {
   }
 
   // ------------------------------------------------------------------------------------------ data
-  int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h) override {
+  // Host -> device copy of this engine's `n` local records of `rec` bytes.  split == nullptr: one contiguous copy.
+  // Otherwise the engine is shard `split->shard` of `split->nshards` inside a multi-device context (multi.h): its local
+  // block b is global block b * nshards + shard of the caller's buffer, so every block is copied straight from where
+  // the caller has it -- no gathered host copy in between.
+  int copy_h2d(void* dst, const uint8_t* src, size_t rec, uint64_t n, const GenMap* split) {
+    if (!split || split->nshards <= 1) {
+      MSMZ_HIP(hipMemcpyAsync(dst, src, n * rec, hipMemcpyHostToDevice, stream_));
+      return MSMZ_OK;
+    }
+    const uint64_t blk = 1ull << split->blk_shift;
+    for (uint64_t li = 0; li < n; li += blk) {
+      const uint64_t len = n - li < blk ? n - li : blk;
+      const uint64_t gi = ((li >> split->blk_shift) * split->nshards + split->shard) << split->blk_shift;
+      MSMZ_HIP(hipMemcpyAsync((uint8_t*)dst + li * rec, src + gi * rec, len * rec, hipMemcpyHostToDevice, stream_));
+    }
+    return MSMZ_OK;
+  }
+
+  int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h, const GenMap* split = nullptr) override {
     if (!xy || !h || n == 0 || n >= (1ull << (Cfg::HAS_ENDO ? 29 : 30))) return MSMZ_ERR_ARG;   // record indices (incl. endomorphism images) fit 30 bits
     MSMZ_HIP(hipSetDevice(device_));
     int st = stage_.ensure(n * RW * 4 + n);
     if (st) return st;
-    MSMZ_HIP(hipMemcpyAsync(stage_.p, xy, n * RW * 4, hipMemcpyHostToDevice, stream_));
+    if ((st = copy_h2d(stage_.p, xy, (size_t)RW * 4, n, split))) return st;
     uint8_t* d_inf = nullptr;
     if (inf) {
       d_inf = stage_.as<uint8_t>() + n * RW * 4;
-      MSMZ_HIP(hipMemcpyAsync(d_inf, inf, n, hipMemcpyHostToDevice, stream_));
+      if ((st = copy_h2d(d_inf, inf, 1, n, split))) return st;
     }
     const bool endo = Cfg::HAS_ENDO;
     void* dev = nullptr;
@@ -210,12 +263,15 @@ class Engine : public IEngine {
     return MSMZ_OK;
   }
 
-  int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h) override {
+  int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h, const GenMap* split = nullptr) override {
     if (!s || !h || n == 0) return MSMZ_ERR_ARG;
     MSMZ_HIP(hipSetDevice(device_));
     void* dev = nullptr;
     MSMZ_HIP(hipMalloc(&dev, n * 32));
-    MSMZ_HIP(hipMemcpyAsync(dev, s, n * 32, hipMemcpyHostToDevice, stream_));
+    if (int st = copy_h2d(dev, s, 32, n, split)) {
+      (void)hipFree(dev);
+      return st;
+    }
     MsmMeta* d_meta = meta_.as<MsmMeta>();
     MSMZ_HIP(hipMemsetAsync(&d_meta->error, 0, 4, stream_));
     hipLaunchKernelGGL((k_check_scalars<Fr>), dim3((n + 255) / 256), dim3(256), 0, stream_, &d_meta->error,
@@ -271,7 +327,10 @@ class Engine : public IEngine {
   int download_points(uint64_t hd, uint64_t first, uint64_t count, uint8_t* xy, uint8_t* inf) override {
     auto it = handles_.find(hd);
     if (it == handles_.end() || it->second.kind != 0 || !xy) return MSMZ_ERR_ARG;
-    if (first + count > it->second.n * (it->second.has_endo ? 2 : 1)) return MSMZ_ERR_ARG;
+    {
+      const uint64_t have = it->second.n * (it->second.has_endo ? 2 : 1);   // the endomorphism images stay readable
+      if (first > have || count > have - first) return MSMZ_ERR_ARG;        // (no first + count: it can wrap)
+    }
     if (count == 0) return MSMZ_OK;
     MSMZ_HIP(hipSetDevice(device_));
     int st = stage_.ensure(count * RW * 4);
@@ -298,7 +357,9 @@ class Engine : public IEngine {
 
   int download_scalars(uint64_t hd, uint64_t first, uint64_t count, uint8_t* s) override {
     auto it = handles_.find(hd);
-    if (it == handles_.end() || it->second.kind != 1 || !s || first + count > it->second.n) return MSMZ_ERR_ARG;
+    if (it == handles_.end() || it->second.kind != 1 || !s) return MSMZ_ERR_ARG;
+    if (first > it->second.n || count > it->second.n - first) return MSMZ_ERR_ARG;
+    if (count == 0) return MSMZ_OK;
     MSMZ_HIP(hipSetDevice(device_));
     MSMZ_HIP(hipMemcpy(s, (const uint8_t*)it->second.dev + first * 32, count * 32, hipMemcpyDeviceToHost));
     return MSMZ_OK;
@@ -318,7 +379,7 @@ class Engine : public IEngine {
   static constexpr uint64_t kMaxEntriesPerPass = 1ull << 24;
 
   int msm(uint64_t ph, const uint8_t* host_scalars, uint64_t sh, uint64_t n, const msmz_opts* o, uint8_t* out,
-          int* out_inf, msmz_log* log) override {
+          int* out_inf, msmz_log* log, const GenMap* split = nullptr) override {
     auto t_begin = std::chrono::steady_clock::now();
     if (!out || !out_inf || n == 0) return MSMZ_ERR_ARG;
     auto pit = handles_.find(ph);
@@ -336,7 +397,7 @@ class Engine : public IEngine {
       // range (< group order) is checked on the device while the scalars are sliced
       int st = stage_.ensure(n * 32);
       if (st) return st;
-      MSMZ_HIP(hipMemcpyAsync(stage_.p, host_scalars, n * 32, hipMemcpyHostToDevice, stream_));
+      if ((st = copy_h2d(stage_.p, host_scalars, 32, n, split))) return st;
       d_scalars = stage_.as<uint32_t>();
     } else {
       auto sit = handles_.find(sh);
@@ -359,8 +420,13 @@ class Engine : public IEngine {
       msmz_log* lp = log ? &plog : nullptr;
       if (lp) memset(lp, 0, sizeof(*lp));
       st = Cfg::run_msm(*this, pts, d_points, d_sc, cnt, opt, done == 0 ? out : part, done == 0 ? out_inf : &pinf, lp, 0);
-      if (st == MSMZ_ERR_RETRY_BITS)   // a GLV half longer than the assumed bound: one more scalar bit
+      if (st == MSMZ_ERR_RETRY_BITS) {
+        // a GLV half longer than the assumed 127 bits (k_hist flags it): redo with windows for the PROVEN bound
+        // (Fr::GLV_PROVEN_BITS, tools/gen_constants.py), which no half can exceed -- a second flag is an internal error
+        retries_++;
         st = Cfg::run_msm(*this, pts, d_points, d_sc, cnt, opt, done == 0 ? out : part, done == 0 ? out_inf : &pinf, lp, 1);
+        if (st == MSMZ_ERR_RETRY_BITS) st = MSMZ_ERR_ARG;
+      }
       if (st) break;
       if (done > 0) {
         uint8_t acc[RW * 4];
@@ -401,6 +467,14 @@ class Engine : public IEngine {
     *d_out = stage_.as<uint8_t>() + ((in_bytes + 255) & ~(size_t)255);
     return MSMZ_OK;
   }
+
+  int test_set_glv_bits(int bits) override {
+    if (!Fr::HAS_GLV) return MSMZ_ERR_UNSUPPORTED;
+    if (bits != 0 && (bits < 8 || bits > Fr::GLV_BITS - 1)) return MSMZ_ERR_ARG;
+    glv_bits_assumed_ = bits;
+    return MSMZ_OK;
+  }
+  int test_retries() override { return retries_; }
 
   int test_field(int op, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) override {
     if (!a || !b || !out || n == 0 || n > (1u << 22)) return MSMZ_ERR_ARG;
@@ -645,8 +719,17 @@ class Engine : public IEngine {
     pl.n = (uint32_t)n64;
     pl.glv = glv;
     pl.M = glv ? 2 * pl.n : pl.n;
-    pl.b = (glv ? Fr::GLV_BITS - 1 : Fr::BITS) + extra_bits;   // scalar bit length (GLV halves: |s_j| < 2^127 is observed, not
-                                                               // proven -- k_hist flags a longer half and the MSM is redone with +1)
+    // scalar bit length.  GLV halves: first attempt assumes |s_j| < 2^127 (every half seen so far; for BLS12-377 the
+    // analytic bound is 2^126); k_hist flags a longer half and the MSM is redone (extra_bits = 1) with the proven bound
+    // GLV_PROVEN_BITS <= 128, which also is what the 4-word halves of glv_decompose can hold.
+    static_assert(!Fr::HAS_GLV || (Fr::GLV_PROVEN_BITS <= 128 && Fr::GLV_PROVEN_BITS <= Fr::GLV_BITS), "GLV halves must fit 4 words");
+    if (!glv) {
+      pl.b = Fr::BITS;
+    } else if (extra_bits) {
+      pl.b = Fr::GLV_PROVEN_BITS > Fr::GLV_BITS - 1 ? Fr::GLV_PROVEN_BITS : Fr::GLV_BITS - 1;
+    } else {
+      pl.b = glv_bits_assumed_ > 0 ? glv_bits_assumed_ : Fr::GLV_BITS - 1;
+    }
     pl.c = opt.c > 0 ? opt.c : choose_window(glv, pl.M, pl.b, tree_rounds);
     if (pl.c < 2) pl.c = 2;
     if (pl.c > 24) pl.c = 24;
@@ -711,15 +794,13 @@ class Engine : public IEngine {
       MSMZ_HIP(hipGetLastError());
       {
         const uint32_t grid = tiles;
-        const size_t lds = (size_t)3 * nbins * 4;
+        const size_t lds = (size_t)3 * nbins * 4;   // <= kCoarseLdsMax (nbins <= SORT_MAX_BINS): the limit init() raised
         if (pl.glv) {
           if constexpr (Fr::HAS_GLV) {
-            if (lds > 32768) MSMZ_HIP(hipFuncSetAttribute((const void*)k_coarse<Fr, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_coarse<Fr, true>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
                                d_cursor, bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
           }
         } else {
-          if (lds > 32768) MSMZ_HIP(hipFuncSetAttribute((const void*)k_coarse<Fr, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           hipLaunchKernelGGL((k_coarse<Fr, false>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
                              d_cursor, bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
         }
@@ -728,15 +809,7 @@ class Engine : public IEngine {
       mark(pl);  // 3
       MSMZ_HIP(hipGetLastError());
       {
-        const size_t lds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
-        if (!fine_attr_set_) {   // the attribute is per device: set once per engine
-          // (seen once on a fresh box: the first call returned "invalid argument" and the next one succeeded)
-          if (hipFuncSetAttribute((const void*)k_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            MSMZ_HIP(hipFuncSetAttribute((const void*)k_fine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          }
-          fine_attr_set_ = true;
-        }
+        const size_t lds = kFineLds;
         hipLaunchKernelGGL(k_fine, dim3(nbins), dim3(FINE_T), lds, stream_, refs_.as<uint32_t>(), off_.as<uint32_t>(),
                            &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins, idx_bits, n_half,
                            pl.endo_delta);
@@ -1296,7 +1369,8 @@ class Engine : public IEngine {
   bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
   int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
-  bool fine_attr_set_ = false;
+  int retries_ = 0;            // MSMs redone with the proven GLV bound (test hook reads it)
+  int glv_bits_assumed_ = 0;   // test hook (msmz_test_set_glv_bits): assumed bit length of a GLV half; 0 = GLV_BITS - 1
   DevBuf f2desc_, tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};

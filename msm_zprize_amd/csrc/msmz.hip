@@ -171,6 +171,8 @@ int msmz_msm_resident(msmz_ctx* c, uint64_t ph, uint64_t sh, uint64_t n, const m
   return c->engine->msm(ph, nullptr, sh, n, o, out, out_inf, log);
 }
 
+int msmz_test_set_glv_bits(msmz_ctx* c, int bits) { return c ? c->engine->test_set_glv_bits(bits) : MSMZ_ERR_ARG; }
+int msmz_test_retries(msmz_ctx* c) { return c ? c->engine->test_retries() : -1; }
 int msmz_test_field(msmz_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) {
   return c ? c->engine->test_field(op, a, b, n, out) : MSMZ_ERR_ARG;
 }

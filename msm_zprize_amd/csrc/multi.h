@@ -34,16 +34,20 @@ struct GenMap {
 class IEngine {
  public:
   virtual ~IEngine() {}
-  virtual int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h) = 0;
-  virtual int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h) = 0;
+  // `split` (uploads and host-scalar MSMs): the engine is one shard of a multi-device context and `n` counts its LOCAL
+  // records; the host buffer is the caller's whole array, from which the engine copies its own blocks (Engine::copy_h2d)
+  virtual int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h, const GenMap* split = nullptr) = 0;
+  virtual int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h, const GenMap* split = nullptr) = 0;
   virtual int random_points(uint64_t n, uint64_t seed, const GenMap& map, uint64_t* h) = 0;
   virtual int random_scalars(uint64_t n, uint64_t seed, const GenMap& map, uint64_t* h) = 0;
   virtual int download_points(uint64_t h, uint64_t first, uint64_t count, uint8_t* xy, uint8_t* inf) = 0;
   virtual int download_scalars(uint64_t h, uint64_t first, uint64_t count, uint8_t* s) = 0;
   virtual int free_handle(uint64_t h) = 0;
   virtual int msm(uint64_t ph, const uint8_t* host_scalars, uint64_t sh, uint64_t n, const msmz_opts* o, uint8_t* out,
-                  int* out_inf, msmz_log* log) = 0;
+                  int* out_inf, msmz_log* log, const GenMap* split = nullptr) = 0;
   // stage-level test hooks (include/msmz_test.h)
+  virtual int test_set_glv_bits(int) { return MSMZ_ERR_UNSUPPORTED; }
+  virtual int test_retries() { return 0; }
   virtual int test_field(int, const uint8_t*, const uint8_t*, uint64_t, uint8_t*) { return MSMZ_ERR_UNSUPPORTED; }
   virtual int test_glv(const uint8_t*, uint64_t, uint8_t*, uint8_t*, uint8_t*) { return MSMZ_ERR_UNSUPPORTED; }
   virtual int test_digits(const uint8_t*, uint64_t, int, int, int, uint32_t*) { return MSMZ_ERR_UNSUPPORTED; }
@@ -75,33 +79,27 @@ class MultiEngine : public IEngine {
     for (Worker* w : workers_) delete w;
   }
 
-  int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h) override {
+  int upload_points(const uint8_t* xy, const uint8_t* inf, uint64_t n, uint64_t* h, const GenMap* = nullptr) override {
     if (!xy || !h || n == 0) return MSMZ_ERR_ARG;
-    const size_t rec = 2 * (size_t)fb_;
     MHandle mh{0, n, std::vector<uint64_t>(G_, 0)};
     int st = for_all([&](uint32_t g, IEngine* e) {
       const uint64_t cnt = shard_count(n, g, G_);
       if (cnt == 0) return (int)MSMZ_OK;
-      // gather this shard's blocks into one contiguous staging buffer (host copy; upload is not the hot path)
-      std::vector<uint8_t> buf(cnt * rec), fl(inf ? cnt : 0);
-      for_blocks(n, g, [&](uint64_t gi, uint64_t li, uint64_t len) {
-        memcpy(buf.data() + li * rec, xy + gi * rec, len * rec);
-        if (inf) memcpy(fl.data() + li, inf + gi, len);
-      });
-      return e->upload_points(buf.data(), inf ? fl.data() : nullptr, cnt, &mh.sub[g]);
+      // every device copies its own blocks straight out of the caller's buffer (no gathered host copy)
+      const GenMap split{G_, g, MULTI_BLOCK_SHIFT};
+      return e->upload_points(xy, inf, cnt, &mh.sub[g], &split);
     });
     return finish_handle(st, mh, h);
   }
 
-  int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h) override {
+  int upload_scalars(const uint8_t* s, uint64_t n, uint64_t* h, const GenMap* = nullptr) override {
     if (!s || !h || n == 0) return MSMZ_ERR_ARG;
     MHandle mh{1, n, std::vector<uint64_t>(G_, 0)};
     int st = for_all([&](uint32_t g, IEngine* e) {
       const uint64_t cnt = shard_count(n, g, G_);
       if (cnt == 0) return (int)MSMZ_OK;
-      std::vector<uint8_t> buf(cnt * 32);
-      for_blocks(n, g, [&](uint64_t gi, uint64_t li, uint64_t len) { memcpy(buf.data() + li * 32, s + gi * 32, len * 32); });
-      return e->upload_scalars(buf.data(), cnt, &mh.sub[g]);
+      const GenMap split{G_, g, MULTI_BLOCK_SHIFT};
+      return e->upload_scalars(s, cnt, &mh.sub[g], &split);
     });
     return finish_handle(st, mh, h);
   }
@@ -130,7 +128,8 @@ class MultiEngine : public IEngine {
 
   int download_points(uint64_t hd, uint64_t first, uint64_t count, uint8_t* xy, uint8_t* inf) override {
     auto it = handles_.find(hd);
-    if (it == handles_.end() || it->second.kind != 0 || !xy || first + count > it->second.n) return MSMZ_ERR_ARG;
+    if (it == handles_.end() || it->second.kind != 0 || !xy) return MSMZ_ERR_ARG;
+    if (first > it->second.n || count > it->second.n - first) return MSMZ_ERR_ARG;   // (first + count can wrap)
     const size_t rec = 2 * (size_t)fb_;
     return for_range(it->second, first, count, [&](IEngine* e, uint64_t sub, uint64_t li, uint64_t gi, uint64_t len) {
       return e->download_points(sub, li, len, xy + (gi - first) * rec, inf ? inf + (gi - first) : nullptr);
@@ -139,7 +138,8 @@ class MultiEngine : public IEngine {
 
   int download_scalars(uint64_t hd, uint64_t first, uint64_t count, uint8_t* s) override {
     auto it = handles_.find(hd);
-    if (it == handles_.end() || it->second.kind != 1 || !s || first + count > it->second.n) return MSMZ_ERR_ARG;
+    if (it == handles_.end() || it->second.kind != 1 || !s) return MSMZ_ERR_ARG;
+    if (first > it->second.n || count > it->second.n - first) return MSMZ_ERR_ARG;
     return for_range(it->second, first, count, [&](IEngine* e, uint64_t sub, uint64_t li, uint64_t gi, uint64_t len) {
       return e->download_scalars(sub, li, len, s + (gi - first) * 32);
     });
@@ -155,7 +155,7 @@ class MultiEngine : public IEngine {
   }
 
   int msm(uint64_t ph, const uint8_t* host_scalars, uint64_t sh, uint64_t n, const msmz_opts* o, uint8_t* out,
-          int* out_inf, msmz_log* log) override {
+          int* out_inf, msmz_log* log, const GenMap* = nullptr) override {
     if (!out || !out_inf || n == 0) return MSMZ_ERR_ARG;
     auto pit = handles_.find(ph);
     if (pit == handles_.end() || pit->second.kind != 0 || pit->second.n < n) return MSMZ_ERR_ARG;
@@ -175,11 +175,8 @@ class MultiEngine : public IEngine {
       if (cnt == 0) return (int)MSMZ_OK;
       used[g] = 1;
       if (sc) return e->msm(pts.sub[g], nullptr, sc->sub[g], cnt, o, part[g].data(), &pinf[g], &logs[g]);
-      std::vector<uint8_t> buf(cnt * 32);
-      for_blocks(n, g, [&](uint64_t gi, uint64_t li, uint64_t len) {
-        memcpy(buf.data() + li * 32, host_scalars + gi * 32, len * 32);
-      });
-      return e->msm(pts.sub[g], buf.data(), 0, cnt, o, part[g].data(), &pinf[g], &logs[g]);
+      const GenMap split{G_, g, MULTI_BLOCK_SHIFT};   // host scalars: the device copies its own blocks of the caller's buffer
+      return e->msm(pts.sub[g], host_scalars, 0, cnt, o, part[g].data(), &pinf[g], &logs[g], &split);
     });
     if (st) return st;
     // fold the partial sums (the reference's "partition sum" on the main thread, msm-batched-affine.ts:300-307)
@@ -220,6 +217,19 @@ class MultiEngine : public IEngine {
     return MSMZ_OK;
   }
 
+  int test_set_glv_bits(int bits) override {
+    int st = MSMZ_OK;
+    for (Worker* w : workers_) {
+      const int s = w->eng->test_set_glv_bits(bits);
+      if (s && !st) st = s;
+    }
+    return st;
+  }
+  int test_retries() override {
+    int r = 0;
+    for (Worker* w : workers_) r += w->eng->test_retries();
+    return r;
+  }
   int test_field(int op, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) override {
     return workers_[0]->eng->test_field(op, a, b, n, out);
   }
@@ -306,13 +316,6 @@ class MultiEngine : public IEngine {
       if (s && !st) st = s;
     }
     return st;
-  }
-
-  // the blocks of shard g inside the first n entries: fn(global index, local index, length)
-  void for_blocks(uint64_t n, uint32_t g, const std::function<void(uint64_t, uint64_t, uint64_t)>& fn) const {
-    const uint64_t blk = 1ull << MULTI_BLOCK_SHIFT;
-    uint64_t li = 0;
-    for (uint64_t gi = (uint64_t)g * blk; gi < n; gi += blk * G_, li += blk) fn(gi, li, n - gi < blk ? n - gi : blk);
   }
 
   // pieces of the global range [first, first + count): fn(engine, sub handle, local index, global index, length)

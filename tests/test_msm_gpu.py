@@ -377,3 +377,55 @@ def test_batched_affine_bucket_reduction(curves, label):
     s2 = curve.Parallel.scalarsFromBigints(scalars)
     for cc in (2, 3, 5):
         assert curve.Parallel.msm(s2, p2, 5, False, {"glv": 0, "c": cc, "reduceAffine": 1})["result"] == want, cc
+
+
+@pytest.mark.parametrize("label", WEIER)
+def test_glv_half_longer_than_assumed_is_redone(label):
+    """The engine sizes the GLV windows for halves below 2^127 and redoes the MSM with the analytic bound
+    (src/wasm/glv.ts:216-226 `maxBits`; tools/gen_constants.py glv_proven_bits) when the slicing kernel flags a
+    longer half.  No real scalar is known to take that path, so the test hook shrinks the ASSUMED length: ordinary
+    halves overflow, the flag is raised, and the redone MSM must still equal the oracle."""
+    import msm_zprize_amd as m
+    from msm_zprize_amd._native import lib
+    m.startThreads()
+    curve = m.Weierstrass.create(m.curves.BY_LABEL[label])
+    try:
+        n = 300
+        pts = curve.Parallel.randomPointsFast(n, 91)
+        sc = curve.Parallel.randomScalars(n, 92)
+        want = _oracle(label, curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
+        assert lib().msmz_test_retries(curve._ctx) == 0
+        assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 1})["result"] == want
+        assert lib().msmz_test_retries(curve._ctx) == 0            # the default bound holds for ordinary scalars
+        for bits, c in ((100, 0), (64, 7), (110, 13)):   # K * c stays below the halves' ~126 bits
+            assert lib().msmz_test_set_glv_bits(curve._ctx, bits) == 0
+            before = lib().msmz_test_retries(curve._ctx)
+            assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 1, "c": c})["result"] == want, (bits, c)
+            assert curve.Parallel.msm(sc, pts, n, False, {"glv": 1, "c": c})["result"] == want, (bits, c)
+            assert lib().msmz_test_retries(curve._ctx) == before + 2, (bits, c)   # both MSMs took the redo path
+        assert lib().msmz_test_set_glv_bits(curve._ctx, 0) == 0
+        before = lib().msmz_test_retries(curve._ctx)
+        assert curve.Parallel.msmUnsafe(sc, pts, n, False, {"glv": 1})["result"] == want
+        assert lib().msmz_test_retries(curve._ctx) == before
+        assert lib().msmz_test_set_glv_bits(curve._ctx, 4) == 1 and lib().msmz_test_set_glv_bits(curve._ctx, 128) == 1
+    finally:
+        curve.close()
+
+
+def test_download_ranges_cannot_wrap(curves):
+    """first + count is checked without 64-bit wrap-around (a C caller could pass first = 2^64 - 1, count = 2)"""
+    import ctypes as C
+    from msm_zprize_amd._native import lib
+    curve = curves("bls12-377")
+    pts = curve.Parallel.randomPointsFast(8, 5)
+    sc = curve.Parallel.randomScalars(8, 5)
+    buf = C.create_string_buffer(96 * 8)
+    big = (1 << 64) - 1
+    assert lib().msmz_download_points(curve._ctx, pts.handle, big, 2, buf, None) == 1
+    assert lib().msmz_download_points(curve._ctx, pts.handle, 2, big, buf, None) == 1
+    assert lib().msmz_download_points(curve._ctx, pts.handle, 17, 0, buf, None) == 1    # beyond the images too
+    assert lib().msmz_download_points(curve._ctx, pts.handle, 8, 8, buf, None) == 0     # the endomorphism images
+    assert lib().msmz_download_scalars(curve._ctx, sc.handle, big, 2, buf) == 1
+    assert lib().msmz_download_scalars(curve._ctx, sc.handle, 7, 2, buf) == 1
+    assert lib().msmz_download_scalars(curve._ctx, sc.handle, 7, 1, buf) == 0
+    pts.free(); sc.free()

@@ -24,6 +24,23 @@ def mod():
     return m
 
 
+def test_first_msm_of_a_context_at_2e24(mod):
+    """A fresh context whose FIRST MSM runs the sort at its largest LDS footprints: 2^24 points leave 7 fine bits, so
+    k_coarse stages 8192 bins (96 KB of dynamic LDS on top of 32.8 KB static) and k_fine its full 156 KB.  The LDS
+    limits are raised once in Engine::init(); nothing is retried (round 2 hid an `invalid argument` behind a second
+    attempt).  Closed form as below."""
+    curve = mod.Weierstrass.create(mod.curves.bls12377Params)
+    try:
+        n = 1 << 24
+        pts = curve.Parallel.randomPointsFast(n, 41)
+        sc = curve.Parallel.randomScalars(n, 42)
+        out = curve.Parallel.msmUnsafe(sc, pts, n, True, {"glv": 0})
+        assert _strip(out["result"]) == _expected("bls12-377", 41, 42, n)
+        assert out["stats"].c == 17 and out["stats"].K == 15
+    finally:
+        curve.close()
+
+
 def _expected(label, pseed, sseed, n):
     c = P.CURVES[label]
     q = c["order"]

@@ -71,6 +71,22 @@ def glv_device_constants(q, lam):
                 sgn=(sg(v00) * sg(m0), sg(v01) * sg(m1), sg(v10) * sg(m0), sg(v11) * sg(m1)))
 
 
+def glv_proven_bits(q, c):
+    """Analytic bound on the halves, the counterpart of maxS0 / maxS1 of the reference (src/wasm/glv.ts:216-226), in
+    exact rational arithmetic.  The real solution of  V x = (-s, 0)  is x*_0 = -s v11 / det, x*_1 = s v10 / det.  The
+    device computes x_j = round(|m_j| s / 2^256) with m_j = trunc(2^256 (-v11 | v10) / det): the truncation moves
+    m_j by less than 1, hence x_j by less than s / 2^256 < q / 2^256, and the rounding by at most 1/2, so
+        |x_j - x*_j| < E = 1/2 + q / 2^256,
+        |s0| = |v00 e0 + v01 e1| < (|v00| + |v01|) E,   |s1| < (|v10| + |v11|) E.
+    Returns the bit length that bound implies (so |s_j| < 2^bits for EVERY scalar < q)."""
+    from fractions import Fraction
+    import math
+    v00, v01, v10, v11 = c["v"]
+    E = Fraction(1, 2) + Fraction(q, 1 << 256)
+    bound = max((abs(v00) + abs(v01)) * E, (abs(v10) + abs(v11)) * E)
+    return int(math.ceil(bound)).bit_length()
+
+
 def glv_decompose_model(s, q, lam, c):
     """Integer model of the device kernel (used to bound |s_i| and as a self-check)."""
     v00, v01, v10, v11 = c["v"]
@@ -154,8 +170,11 @@ def main():
                 assert (s0 + s1 * lam - s) % q == 0
                 mx = max(mx, abs(s0), abs(s1))
             assert mx < (1 << 127), mx.bit_length()
+            proven = glv_proven_bits(q, g)
+            assert mx.bit_length() <= proven <= 128, (mx.bit_length(), proven)   # 4-word halves can never truncate
             L.append("  static constexpr bool HAS_GLV = true;")
-            L.append("  static constexpr int GLV_BITS = 128;  // |s0|,|s1| < 2^127 observed bound %d bits" % mx.bit_length())
+            L.append("  static constexpr int GLV_BITS = 128;  // windows cover GLV_BITS bits: halves below 2^127 (observed: %d bits) never overflow them" % mx.bit_length())
+            L.append("  static constexpr int GLV_PROVEN_BITS = %d;  // analytic bound (tools/gen_constants.py glv_proven_bits; cf. src/wasm/glv.ts:216-226): |s0|, |s1| < 2^%d for every scalar" % (proven, proven))
             L.append("  static constexpr int GLV_TYP_BITS = %d;  // bit length of the largest half seen in 20000 samples (bucket-balance heuristic only)" % mx.bit_length())
             v00, v01, v10, v11 = g["v"]
             L.append(arr("GLV_V00", limbs(abs(v00), 4)))
@@ -170,6 +189,7 @@ def main():
         else:
             L.append("  static constexpr bool HAS_GLV = false;")
             L.append("  static constexpr int GLV_BITS = 0;")
+            L.append("  static constexpr int GLV_PROVEN_BITS = 0;")
             L.append("  static constexpr int GLV_TYP_BITS = 0;")
         L.append("};")
         L.append("")
