@@ -13,15 +13,23 @@ export interface ParallelApi {
   randomScalars(n: number, options?: { seed?: bigint | number }): Promise<DeviceArray>;
   pointsFromBytes(bytes: Uint8Array, n?: number, isInf?: Uint8Array): Promise<DeviceArray>;
   scalarsFromBytes(bytes: Uint8Array, n?: number): Promise<DeviceArray>;
-  msm(scalars: DeviceArray | Uint8Array, points: DeviceArray, n: number, verbose?: boolean, options?: MsmOptions): Promise<MsmResult>;
-  msmUnsafe(scalars: DeviceArray | Uint8Array, points: DeviceArray, n: number, verbose?: boolean, options?: MsmOptions): Promise<MsmResult>;
+  /** pointer-style routes of src/parallel.ts:89-133: pointers are numbers in a virtual address space */
+  getPointer(size: number): Promise<number>;
+  getScalarPointer(size: number): Promise<number>;
+  pointsFromBytes(pointPtr: number, pointInputPtr: number, n: number): Promise<void>;
+  scalarsFromBytes(scalarPtr: number, scalarInputPtr: number, n: number): Promise<void>;
+  msm(scalars: DeviceArray | Uint8Array | number, points: DeviceArray | number, n: number, verbose?: boolean, options?: MsmOptions): Promise<MsmResult>;
+  msmUnsafe(scalars: DeviceArray | Uint8Array | number, points: DeviceArray | number, n: number, verbose?: boolean, options?: MsmOptions): Promise<MsmResult>;
   msmProjective?(scalars: DeviceArray | Uint8Array, points: DeviceArray, n: number, options?: MsmOptions): Promise<MsmResult>;
 }
 export interface MsmCurve {
   params: CurveParams; Parallel: ParallelApi;
-  Scalar: { modulus: bigint; sizeInBits: number; readBigint(a: DeviceArray, i?: number): bigint; toBigints(a: DeviceArray, first?: number, count?: number): bigint[]; fromBigints(s: bigint[]): Promise<DeviceArray> };
-  Affine: { size: number; toBigint(p: BigintPoint): BigintPoint; toBigints(a: DeviceArray, first?: number, count?: number): BigintPoint[]; fromBigints(p: BigintPoint[]): Promise<DeviceArray> };
-  Projective: { toAffine(scratch: unknown, affPtr: unknown, result: BigintPoint): BigintPoint; toBigint(r: BigintPoint): BigintPoint };
+  Field: { sizeField: number; memoryBytes: { set(bytes: Uint8Array, ptr: number): void }; isEqual(a: number, b: number): boolean;
+           local: { getPointers(n: number): number[]; getPointer(size: number): number } };
+  Scalar: { sizeField: number; memoryBytes: { set(bytes: Uint8Array, ptr: number): void }; writeBigint(ptr: number, s: bigint): void;
+            modulus: bigint; sizeInBits: number; readBigint(a: DeviceArray, i?: number): bigint; toBigints(a: DeviceArray, first?: number, count?: number): bigint[]; fromBigints(s: bigint[]): Promise<DeviceArray> };
+  Affine: { size: number; toBigint(p: BigintPoint | number): BigintPoint; writeBigints(ptr: number, points: BigintPoint[]): number; toBigints(a: DeviceArray, first?: number, count?: number): BigintPoint[]; fromBigints(p: BigintPoint[]): Promise<DeviceArray> };
+  Projective: { toAffine(scratch: unknown, affPtr: number | null, result: BigintPoint): BigintPoint; toBigint(r: BigintPoint): BigintPoint };
   pointAdd(a: BigintPoint, b: BigintPoint): BigintPoint; close(): void;
 }
 /** n = number of GPUs a curve context drives (inputs split over them); deviceId = first GPU or an explicit list */
