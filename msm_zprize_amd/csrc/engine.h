@@ -147,7 +147,7 @@ class Engine : public IEngine {
   static constexpr int XW = 4 * NW;      // XYZZ / extended record words
   static constexpr int FE_BYTES = NW * 4;
   static constexpr bool TE = Cfg::TE;
-  static constexpr int PW_WORDS = TE ? 4 * NW : 2 * NW;   // device point record words
+  static constexpr int PW_WORDS = TE ? 4 * NW : PointFmt<F>::STRIDE;   // words between the records of a resident point set
 
  public:
   explicit Engine(int device) : device_(device) {}

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(128) k_gen_points(uint32_t* out, const uint32_
   Affine<F> r;
   bool inf = xyzz_is_inf(acc);
   if (!inf) xyzz_to_affine_mont(r, acc);
-  store_affine<F>(out + (size_t)i * RW, r, inf);
+  store_affine<F>(out + (size_t)i * PointFmt<F>::STRIDE, r, inf);
   if (endo) {
     Fe<F> beta, bx;
     fe_set_const<F>(beta, F::BETA);
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(128) k_gen_points(uint32_t* out, const uint32_
       fe_mul(bx, r.x, beta);
       r.x = bx;
     }
-    store_affine<F>(out + ((size_t)n + i) * RW, r, inf);
+    store_affine<F>(out + ((size_t)n + i) * PointFmt<F>::STRIDE, r, inf);
   }
 }
 

@@ -51,6 +51,20 @@ struct MsmMeta {               // small device-resident block of run-time totals
 // ------------------------------------------------------------------------------------------------ loads
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Resident point sets: record i of a set starts at word i * PointFmt<F>::STRIDE.  A 96-byte record [x | y] of the
+// 377/381-bit curves is padded to 128 bytes: packed back to back, every second record starts in the middle of a 64-byte
+// sector, so the x-only gathers of the tree rounds' forward pass (48 bytes) touched 1.5 sectors on average and a whole
+// record 2.5 of 128-byte-line granularity; at 128-byte stride x is ONE sector and the record one line.  Memory is the
+// cheap side (288 GB).  The 64-byte records of the 255-bit curves already are one sector.  Wire-format staging buffers
+// (uploads / downloads) stay packed.
+#ifndef MSMZ_POINT_PAD
+#define MSMZ_POINT_PAD 1
+#endif
+template <class F>
+struct PointFmt {
+  static constexpr int STRIDE = (MSMZ_POINT_PAD && 2 * F::NW == 24) ? 32 : 2 * F::NW;   // 32-bit words
+};
+
 // NT = non-temporal access.  Measured (round 1): streaming the tree rounds' slot records past the caches makes
 // k_batch_add 1.7x SLOWER (round 0: 1.9 -> 3.9 ms) -- the backward pass re-reads what the forward pass parked
 // (z, x1) and lives off L2 / Infinity Cache hits -- so SLOT_NT stays false.
@@ -277,13 +291,13 @@ __global__ void __launch_bounds__(256) k_points_to_mont(uint32_t* out, const uin
   bool flagged = is_inf != nullptr && is_inf[i] != 0;
   fe_to_mont(m.x, p.x);
   fe_to_mont(m.y, p.y);
-  store_affine<F>(out + (size_t)i * 2 * F::NW, m, flagged);
+  store_affine<F>(out + (size_t)i * PointFmt<F>::STRIDE, m, flagged);
   if (endo) {
     Fe<F> beta, bx;
     fe_set_const<F>(beta, F::BETA);
     fe_mul(bx, m.x, beta);
     m.x = bx;
-    store_affine<F>(out + ((size_t)n + i) * 2 * F::NW, m, flagged);
+    store_affine<F>(out + ((size_t)n + i) * PointFmt<F>::STRIDE, m, flagged);
   }
 }
 
@@ -293,7 +307,7 @@ __global__ void __launch_bounds__(256) k_points_from_mont(uint32_t* out, const u
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> p;
-  bool inf = load_affine<F>(p, in + (size_t)i * 2 * F::NW, 0);
+  bool inf = load_affine<F>(p, in + (size_t)i * PointFmt<F>::STRIDE, 0);
   uint32_t w[2 * F::NW];
   if (inf) {
 #pragma unroll
@@ -537,7 +551,7 @@ __device__ __forceinline__ const uint32_t* operand_address(uint32_t loc, const u
   const bool orig = (loc & LOC_ORIG) != 0;
   cs = orig ? 1 : SLOT_CS;
   neg = orig ? loc >> 31 : 0u;
-  return orig ? points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW) : slots + slot_offset<F>(loc);
+  return orig ? points + (size_t)(loc & 0x3fffffffu) * PointFmt<F>::STRIDE : slots + slot_offset<F>(loc);
 }
 
 template <class F, bool CHECK_INF>
@@ -561,7 +575,7 @@ __device__ __forceinline__ bool load_operand(Affine<F>& p, uint32_t loc, const u
   } else {
     if (loc & LOC_ORIG) {
       uint32_t w[2 * F::NW];
-      load_words<F>(w, points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
+      load_words<F>(w, points + (size_t)(loc & 0x3fffffffu) * PointFmt<F>::STRIDE);
       uint32_t o = 0;
       if (CHECK_INF) {
 #pragma unroll
@@ -619,7 +633,7 @@ __device__ __forceinline__ void load_operand_x(Fe<F>& x, uint32_t loc, const uin
   } else {
     if (loc & LOC_ORIG) {
       uint32_t w[F::NW];
-      const u32x4* s4 = reinterpret_cast<const u32x4*>(points + (size_t)(loc & 0x3fffffffu) * (2 * F::NW));
+      const u32x4* s4 = reinterpret_cast<const u32x4*>(points + (size_t)(loc & 0x3fffffffu) * PointFmt<F>::STRIDE);
 #pragma unroll
       for (int i = 0; i < F::NW / 4; i++) {
         const u32x4 v = s4[i];
@@ -936,7 +950,7 @@ template <class F_>
 struct WeierPolicy {
   using F = F_;
   using Acc = Xyzz<F>;
-  static constexpr int IN_WORDS = 2 * F::NW;
+  static constexpr int IN_WORDS = PointFmt<F>::STRIDE;   // words between the records of a resident point set
   static constexpr int ACC_WORDS = 4 * F::NW;
   static __device__ __forceinline__ void zero(Acc& a) { xyzz_set_inf(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { xyzz_add(r, a, b); }
