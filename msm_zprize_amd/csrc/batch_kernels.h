@@ -191,25 +191,28 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     }
   }
   __syncthreads();
+  // down-sweep: one thread per CHILD (inverse of a child = inverse of the parent times the sibling), so a level is one
+  // field product deep, not two (the sweep is on the critical path of every batch: ~1.8 us per product when the
+  // workgroup's other waves wait at the barrier)
 #pragma unroll 1
   for (int width = 1; width <= T >> 2; width <<= 1) {
     const int parent_off = lvl_off;
     lvl_off -= width * 2;
-    if ((int)threadIdx.x < width) {
-      Fe<F> pi, x, y, xi, yi;
+    Fe<F> ci;
+    const bool mine = (int)threadIdx.x < 2 * width;
+    if (mine) {
+      Fe<F> pi, sib;
 #pragma unroll
       for (int j = 0; j < N; j++) {
-        pi.l[j] = tree[j * T + parent_off + threadIdx.x];
-        x.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x];
-        y.l[j] = tree[j * T + lvl_off + 2 * threadIdx.x + 1];
+        pi.l[j] = tree[j * T + parent_off + (threadIdx.x >> 1)];
+        sib.l[j] = tree[j * T + lvl_off + (threadIdx.x ^ 1)];
       }
-      fe_mul(xi, pi, y);
-      fe_mul(yi, pi, x);
+      fe_mul(ci, pi, sib);
+    }
+    __syncthreads();   // every sibling has been read before a child is overwritten
+    if (mine) {
 #pragma unroll
-      for (int j = 0; j < N; j++) {
-        tree[j * T + lvl_off + 2 * threadIdx.x] = xi.l[j];
-        tree[j * T + lvl_off + 2 * threadIdx.x + 1] = yi.l[j];
-      }
+      for (int j = 0; j < N; j++) tree[j * T + lvl_off + threadIdx.x] = ci.l[j];
     }
     __syncthreads();
   }
