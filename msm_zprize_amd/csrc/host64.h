@@ -87,51 +87,66 @@ struct Host64 {
     if (sub_n(r.l, a.l, b.l)) add_n(r.l, r.l, p);
   }
 
-  // r = a * b / 2^RBITS mod p
+  // r = a * b / 2^RBITS mod p: word-interleaved (CIOS) Montgomery product, NL full word steps and one partial step of
+  // TAIL bits, fixed trip counts throughout (the Horner tail of an MSM is ~2500 of these in a dependent chain).
   void mul(E& r, const E& a, const E& b) const {
-    uint64_t t[2 * NL + 2];
-    memset(t, 0, sizeof(t));
+    uint64_t t[NL + 2];
+    for (int j = 0; j < NL + 2; j++) t[j] = 0;
+#if defined(__clang__)
+#pragma unroll
+#endif
     for (int i = 0; i < NL; i++) {
+      // t += a_i * b
       uint64_t c = 0;
+      const uint64_t ai = a.l[i];
+#if defined(__clang__)
+#pragma unroll
+#endif
       for (int j = 0; j < NL; j++) {
-        const u128 s = (u128)a.l[i] * b.l[j] + t[i + j] + c;
-        t[i + j] = (uint64_t)s;
+        const u128 s = (u128)ai * b.l[j] + t[j] + c;
+        t[j] = (uint64_t)s;
         c = (uint64_t)(s >> 64);
       }
-      t[i + NL] = c;
+      {
+        const u128 s = (u128)t[NL] + c;
+        t[NL] = (uint64_t)s;
+        t[NL + 1] = (uint64_t)(s >> 64);
+      }
+      // t = (t + m p) / 2^64 with m = t_0 * (-p^-1) mod 2^64
+      const uint64_t m = t[0] * pinv;
+      c = (uint64_t)(((u128)m * p[0] + t[0]) >> 64);
+#if defined(__clang__)
+#pragma unroll
+#endif
+      for (int j = 1; j < NL; j++) {
+        const u128 s = (u128)m * p[j] + t[j] + c;
+        t[j - 1] = (uint64_t)s;
+        c = (uint64_t)(s >> 64);
+      }
+      {
+        const u128 s = (u128)t[NL] + c;
+        t[NL - 1] = (uint64_t)s;
+        t[NL] = t[NL + 1] + (uint64_t)(s >> 64);
+      }
     }
-    // NL full word steps: t += m * p * 2^(64 i) with m = t_i * (-p^-1) mod 2^64
-    for (int i = 0; i < NL; i++) {
-      const uint64_t m = t[i] * pinv;
-      uint64_t c = 0;
-      for (int j = 0; j < NL; j++) {
-        const u128 s = (u128)m * p[j] + t[i + j] + c;
-        t[i + j] = (uint64_t)s;
-        c = (uint64_t)(s >> 64);
-      }
-      for (int k = i + NL; c != 0 && k < 2 * NL + 2; k++) {
-        const u128 s = (u128)t[k] + c;
-        t[k] = (uint64_t)s;
-        c = (uint64_t)(s >> 64);
-      }
-    }
-    // partial step: clear the low TAIL bits of t[NL]
+    // partial step: clear the low TAIL bits, then shift them out; the result is < 2p
     {
-      const uint64_t m = (t[NL] * pinv) & (((uint64_t)1 << TAIL) - 1);
+      const uint64_t m = (t[0] * pinv) & (((uint64_t)1 << TAIL) - 1);
       uint64_t c = 0;
+#if defined(__clang__)
+#pragma unroll
+#endif
       for (int j = 0; j < NL; j++) {
-        const u128 s = (u128)m * p[j] + t[NL + j] + c;
-        t[NL + j] = (uint64_t)s;
+        const u128 s = (u128)m * p[j] + t[j] + c;
+        t[j] = (uint64_t)s;
         c = (uint64_t)(s >> 64);
       }
-      for (int k = 2 * NL; c != 0 && k < 2 * NL + 2; k++) {
-        const u128 s = (u128)t[k] + c;
-        t[k] = (uint64_t)s;
-        c = (uint64_t)(s >> 64);
-      }
+      t[NL] += c;
     }
-    // shift right by RBITS = 64 NL + TAIL; the result is < 2p
-    for (int j = 0; j < NL; j++) r.l[j] = (t[NL + j] >> TAIL) | (t[NL + j + 1] << (64 - TAIL));
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NL; j++) r.l[j] = (t[j] >> TAIL) | (t[j + 1] << (64 - TAIL));
     if (geq(r.l, p)) sub_n(r.l, r.l, p);
   }
   void sqr(E& r, const E& a) const { mul(r, a, a); }
