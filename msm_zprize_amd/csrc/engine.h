@@ -157,7 +157,7 @@ class Engine : public IEngine {
     MSMZ_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     for (auto& e : ev_) MSMZ_HIP(hipEventCreate(&e));
     MSMZ_HIP(hipHostMalloc(&h_meta_, sizeof(MsmMeta)));
-    MSMZ_HIP(hipHostMalloc(&h_final_, (size_t)2 * kMaxWindows * XW * 4));
+    MSMZ_HIP(hipHostMalloc(&h_final_, (size_t)3 * kMaxWindows * XW * 4));   // [kMaxWindows | up to 2 * kMaxWindows results]
     // Kernels that stage more than the default dynamic-LDS allowance get their limit raised ONCE, here, right after
     // hipSetDevice -- not lazily inside the first MSM and not on every MSM.  static + dynamic LDS is checked against
     // the device's per-workgroup LDS, so a kernel that cannot launch fails context creation with its name.
@@ -870,16 +870,17 @@ class Engine : public IEngine {
 
   // reduce levels on accumulator records: rows in red_[cur*2], C in red_[cur*2+1]; ends with one entry per window
   template <class P>
-  int reduce_levels(const Plan& pl, int& cur, uint32_t n_in) {
+  int reduce_levels(const Plan& pl, int& cur, uint32_t n_in, uint32_t nprob = 0) {
     constexpr int AW = P::ACC_WORDS;
     int st;
+    if (nprob == 0) nprob = (uint32_t)pl.Keff;   // independent weighted sums ("windows") the levels run side by side
     while (n_in > tail_n_) {
       const uint32_t S = 4;   // quads handle short tails too
       uint32_t g2 = (n_in + S - 1) / S;
       int nxt = cur ^ 1;
-      if ((st = red_[nxt * 2].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
-      if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.Keff * g2 * AW * 4))) return st;
-      uint32_t total = pl.Keff * g2;
+      if ((st = red_[nxt * 2].ensure((size_t)nprob * g2 * AW * 4))) return st;
+      if ((st = red_[nxt * 2 + 1].ensure((size_t)nprob * g2 * AW * 4))) return st;
+      uint32_t total = nprob * g2;
       if (total <= quad16_max_groups_) {
         // small level: latency-bound, one DPP quad per addition
         hipLaunchKernelGGL((k_reduce_quad16<P>), dim3((total * 16 + 63) / 64), dim3(64), 0, stream_,
@@ -897,10 +898,10 @@ class Engine : public IEngine {
     // window sums in final_
     {
       const int nxt = cur ^ 1;
-      if ((st = red_[nxt * 2].ensure((size_t)pl.Keff * n_in * AW * 4))) return st;
-      if ((st = red_[nxt * 2 + 1].ensure((size_t)pl.Keff * n_in * AW * 4))) return st;
-      if ((st = final_.ensure((size_t)pl.Keff * AW * 4))) return st;
-      hipLaunchKernelGGL((k_reduce_tail<P>), dim3(pl.Keff), dim3(REDUCE_TAIL_T), 0, stream_, red_[cur * 2].as<uint32_t>(),
+      if ((st = red_[nxt * 2].ensure((size_t)nprob * n_in * AW * 4))) return st;
+      if ((st = red_[nxt * 2 + 1].ensure((size_t)nprob * n_in * AW * 4))) return st;
+      if ((st = final_.ensure((size_t)nprob * AW * 4))) return st;
+      hipLaunchKernelGGL((k_reduce_tail<P>), dim3(nprob), dim3(REDUCE_TAIL_T), 0, stream_, red_[cur * 2].as<uint32_t>(),
                          red_[cur * 2 + 1].as<uint32_t>(), red_[nxt * 2].as<uint32_t>(), red_[nxt * 2 + 1].as<uint32_t>(),
                          final_.as<uint32_t>(), n_in, n_in);
     }
@@ -919,11 +920,12 @@ class Engine : public IEngine {
 
   // copy the K window sums (the C entries of the last level; its rows are multiples of L and not needed) to the host
   template <class P>
-  int fetch_window_sums(const Plan& pl, int cur) {
+  int fetch_window_sums(const Plan& pl, int cur, uint32_t nprob = 0) {
     constexpr int AW = P::ACC_WORDS;
     MSMZ_HIP(hipGetLastError());
     (void)cur;
-    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, final_.p, (size_t)pl.Keff * AW * 4,
+    if (nprob == 0) nprob = (uint32_t)pl.Keff;
+    MSMZ_HIP(hipMemcpyAsync(h_final_ + (size_t)kMaxWindows * AW, final_.p, (size_t)nprob * AW * 4,
                             hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipMemcpyAsync(h_meta_, meta_.p, sizeof(MsmMeta), hipMemcpyDeviceToHost, stream_));
     MSMZ_HIP(hipStreamSynchronize(stream_));
@@ -945,6 +947,107 @@ class Engine : public IEngine {
       host64_.load_pt(w, h_final_ + (size_t)(kMaxWindows + k) * XW);   // W_k = C of the last level
       host64_.add_pt(t, acc, w);
       acc = t;
+    }
+    Xyzz<F> fin;
+    host64_.to_xyzz(fin, acc);
+    uint32_t res[RW];
+    bool inf = xyzz_to_affine_canon<F>(res, fin);
+    memcpy(out, res, RW * 4);
+    *out_inf = inf ? 1 : 0;
+  }
+
+  // Two-dimensional bucket reduction (reduce2d_kernels.h): line sums, then the weighted sums over H lines of 2 Keff
+  // problems with the upper-level kernels.  Leaves result 2 kw (rows) / 2 kw + 1 (columns) of bucket set kw in final_.
+  struct Split2d {
+    int a, b;            // c - 1 = a + b: high / low bits of the bucket weight
+    uint32_t H, D, NC;
+  };
+  Split2d split_2d(const Plan& pl) const {
+    Split2d s;
+    s.a = (pl.c - 1 + 1) / 2;
+    s.b = pl.c - 1 - s.a;
+    s.H = 1u << s.a;
+    s.D = 1u << s.b;
+    // chunks per line: so that the partial sums of all lines are ~256 K threads (measured at 2^20: 16 / 32 / 64 chunks ->
+    // reduce stage 0.88 / 0.81 / 0.81 ms), at most 32 per line (5 pair-sum launches), and a chunk holds at least one
+    // bucket along either direction
+    uint32_t nc = 1;
+    while (nc < 32 && nc * 2 <= s.D && (uint64_t)2 * pl.Keff * s.H * nc < (1u << 18)) nc *= 2;
+    if (r2_nc_ > 0) {
+      nc = 1;
+      while (nc < r2_nc_ && nc * 2 <= s.D) nc *= 2;
+    }
+    s.NC = nc;
+    return s;
+  }
+  int reduce_2d(const Plan& pl, const uint32_t* d_points) {
+    using P = WeierPolicy<F>;
+    const Split2d sp = split_2d(pl);
+    R2Geom g;
+    g.L = pl.L;
+    g.H = sp.H;
+    g.D = sp.D;
+    g.NC = sp.NC;
+    g.chr = sp.D / sp.NC;
+    g.chc = sp.H / sp.NC;
+    g.nprob = 2u * (uint32_t)pl.Keff;
+    const uint32_t lines = g.nprob * g.H;
+    const uint32_t total = lines * g.NC;
+    int st;
+    // ping-pong between red_[0] and red_[2] (rows of the level machinery); C inputs of the first level = infinity
+    if ((st = red_[0].ensure((size_t)total * XW * 4))) return st;
+    if ((st = red_[2].ensure((size_t)total * XW * 4))) return st;
+    hipLaunchKernelGGL((k_reduce2d_partial<F>), dim3((total + 127) / 128), dim3(128), 0, stream_, red_[0].as<uint32_t>(),
+                       slots_.as<uint32_t>(), d_points, bfin_.as<uint4>(), g, total);
+    int src = 0;
+    for (uint32_t n = total / 2; n >= lines && g.NC > 1; n /= 2) {
+      const int dst = src ^ 2;
+      if (n <= pairsum_x4_max_) {
+        hipLaunchKernelGGL((k_pairsum_x4<P>), dim3((n * 4 + 63) / 64), dim3(64), 0, stream_, red_[dst].as<uint32_t>(),
+                           red_[src].as<uint32_t>(), n);
+      } else {
+        hipLaunchKernelGGL((k_pairsum<P>), dim3((n + 127) / 128), dim3(128), 0, stream_, red_[dst].as<uint32_t>(),
+                           red_[src].as<uint32_t>(), n);
+      }
+      src = dst;
+      if (n == lines) break;
+    }
+    // upper levels: rows = line sums (weight unit 1), C = infinity (all-zero accumulator records)
+    const int crow = src, ccol = src + 1;
+    if ((st = red_[ccol].ensure((size_t)lines * XW * 4))) return st;
+    MSMZ_HIP(hipMemsetAsync(red_[ccol].p, 0, (size_t)lines * XW * 4, stream_));
+    int cur = crow >> 1;   // reduce_levels addresses rows as red_[cur * 2], C as red_[cur * 2 + 1]
+    if ((st = reduce_levels<P>(pl, cur, g.H, g.nprob))) return st;
+    MSMZ_HIP(hipGetLastError());
+    return MSMZ_OK;
+  }
+  // Horner over the windows with the two results of every bucket set: acc = (acc * 2^(c-b) + A) * 2^b + B
+  void finalize_weierstrass_2d(const Plan& pl, uint8_t* out, int* out_inf) {
+    using H = Host64<F>;
+    typename H::Pt acc, w, t;
+    host64_.set_inf(acc);
+    const Split2d sp = split_2d(pl);
+    auto add_results = [&](int k, int which) {
+      // bucket sets of window k: kw = k below the top window, K-1 .. Keff-1 (its sub-windows) for the top one
+      const int lo = k, hi = (k == pl.K - 1) ? pl.Keff - 1 : k;
+      for (int kw = lo; kw <= hi; kw++) {
+        host64_.load_pt(w, h_final_ + (size_t)(kMaxWindows + 2 * kw + which) * XW);
+        host64_.add_pt(t, acc, w);
+        acc = t;
+      }
+    };
+    for (int k = pl.K - 1; k >= 0; k--) {
+      if (k < pl.K - 1)
+        for (int j = 0; j < pl.c - sp.b; j++) {
+          host64_.dbl(t, acc);
+          acc = t;
+        }
+      add_results(k, 0);   // rows: weight 2^(c k + b)
+      for (int j = 0; j < sp.b; j++) {
+        host64_.dbl(t, acc);
+        acc = t;
+      }
+      add_results(k, 1);   // columns: weight 2^(c k)
     }
     Xyzz<F> fin;
     host64_.to_xyzz(fin, acc);
@@ -1017,7 +1120,8 @@ class Engine : public IEngine {
     if ((st = bfin_.ensure((size_t)nb * 16))) return st;
     // the batched-affine first reduction level (opt.reserved[0] = 1) wants ONE sum per bucket: no rounds skipped
     const bool f2 = opt.reserved[0] == 1 && pl.L >= 2;
-    const int tail_skip = f2 ? 0 : tail_skip_;
+    const bool r2d = !f2 && reduce2d_ && pl.L >= 2;
+    const int tail_skip = f2 ? 0 : (r2d ? tail_skip_2d_ : tail_skip_);
     hipLaunchKernelGGL(k_plan_count, dim3(n_chunks), dim3(PLAN_T), 0, stream_, rscan_.as<uint32_t>(), off_.as<uint32_t>(),
                        nb, n_chunks, d_meta, tail_skip, chunk);
     hipLaunchKernelGGL(k_plan_emit, dim3(n_chunks), dim3(PLAN_T), 0, stream_, desc_.as<uint2>(), bfin_.as<uint4>(),
@@ -1045,8 +1149,22 @@ class Engine : public IEngine {
     const int ev_acc_end = pl.ei;
     mark(pl);
 
-    // ---- bucket reduction: level 1 from affine bucket sums, then XYZZ levels down to one entry per window
+    // ---- bucket reduction
     using P = WeierPolicy<F>;
+    if (r2d) {
+      // two-dimensional: row / column sums of the buckets, then two half-length weighted sums per bucket set
+      if ((st = reduce_2d(pl, d_points))) return st;
+      const int ev_red_end2 = pl.ei;
+      mark(pl);
+      if ((st = fetch_window_sums<P>(pl, 0, 2u * (uint32_t)pl.Keff))) return st;
+      auto t_host2 = std::chrono::steady_clock::now();
+      if (h_meta_->error & 1u) return MSMZ_ERR_DEGENERATE;
+      finalize_weierstrass_2d(pl, out, out_inf);
+      float host_ms2 = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host2).count();
+      fill_log(log, pl, R, n_pairs, ev_plan0, ev_plan1, ev_acc_end, ev_red_end2, round_ev0, host_ms2);
+      return MSMZ_OK;
+    }
+    // level 1 from affine bucket sums, then XYZZ levels down to one entry per window
     uint32_t S1 = first_group_size(pl);
     if (f2) {   // the weight-L bucket is folded into element L/2, which must be the FIRST element of its group
       if (S1 > 8) S1 = 8;
@@ -1368,6 +1486,10 @@ class Engine : public IEngine {
   bool no_spread_ = env_int("MSMZ_NO_SPREAD", 0) != 0;
   bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
+  bool reduce2d_ = env_int("MSMZ_REDUCE2D", 1) != 0;          // two-dimensional bucket reduction (reduce2d_kernels.h); 0 = the grouped running sums
+  int tail_skip_2d_ = env_int("MSMZ_TAIL_SKIP_2D", 1) > 2 ? 2 : env_int("MSMZ_TAIL_SKIP_2D", 1);
+  uint32_t r2_nc_ = (uint32_t)env_int("MSMZ_R2_NC", 0);         // chunks per line (0 = automatic)
+  uint32_t pairsum_x4_max_ = (uint32_t)env_int("MSMZ_PAIRSUM_X4", 16384);   // pair-sum levels with at most this many additions use DPP quads
   int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
   int retries_ = 0;            // MSMs redone with the proven GLV bound (test hook reads it)
   int glv_bits_assumed_ = 0;   // test hook (msmz_test_set_glv_bits): assumed bit length of a GLV half; 0 = GLV_BITS - 1

@@ -53,6 +53,8 @@
                                                   uint32_t, uint32_t, uint32_t);                                 \
   PFX template __global__ void k_reduce_tail<P>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, \
                                                 uint32_t);                                                       \
+  PFX template __global__ void k_pairsum<P>(uint32_t*, const uint32_t*, uint32_t);                               \
+  PFX template __global__ void k_pairsum_x4<P>(uint32_t*, const uint32_t*, uint32_t);                            \
   PFX template __global__ void k_reduce_next<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
                                                 const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t); \
   PFX template __global__ void k_bucket_accumulate<P>(uint32_t*, const uint32_t*, const uint32_t*,               \
@@ -61,6 +63,8 @@
 #define MSMZ_INST_REDUCE(F, Fr, PFX)                                                                              \
   PFX template __global__ void k_reduce_first<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \
                                                  const uint4*, uint32_t, uint32_t, uint32_t, uint32_t);           \
+  PFX template __global__ void k_reduce2d_partial<F>(uint32_t*, const uint32_t*, const uint32_t*, const uint4*,   \
+                                                     R2Geom, uint32_t);                                          \
   PFX template __global__ void k_reduce_affine_finish<F>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,  \
                                                          const uint2*, const uint4*, F2Geom);                     \
   MSMZ_INST_POLICY(WeierPolicy<F>, PFX)

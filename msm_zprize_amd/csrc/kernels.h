@@ -1328,3 +1328,4 @@ __global__ void __launch_bounds__(REDUCE_TAIL_T, 1) k_reduce_tail(uint32_t* r0, 
 }  // namespace msmz
 
 #include "reduce_affine.h"
+#include "reduce2d_kernels.h"
