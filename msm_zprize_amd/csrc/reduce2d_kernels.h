@@ -125,6 +125,87 @@ __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce2d_partial(uint3
   store_xyzz<F>(part + ((size_t)(prob * g.H + line) * g.NC + chunk) * 4 * F::NW, acc);
 }
 
+// The same partial sums for the msmBasic path (msm-basic.ts:106-128 buckets in XYZZ / extended coordinates): bucket g is
+// the sum of the partial accumulators accs[cscan[g] .. cscan[g+1]) that k_bucket_accumulate left of it.
+template <class P>
+__global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce2d_partial_acc(uint32_t* part, const uint32_t* accs,
+                                                                               const uint32_t* cscan, R2Geom g,
+                                                                               uint32_t total) {
+  constexpr int XW = P::ACC_WORDS;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint32_t per_prob = g.H * g.NC;
+  const uint32_t prob = t / per_prob, u = t - prob * per_prob;
+  const uint32_t kw = prob >> 1;
+  const bool col = (prob & 1u) != 0;
+  uint32_t line, chunk, j0 = 0, step = 0, count = 0;
+  if (!col) {
+    line = u / g.NC;
+    chunk = u - line * g.NC;
+    j0 = line * g.D + chunk;
+    step = g.NC;
+    count = g.chr;
+  } else if (u < g.D * g.NC) {
+    chunk = u / g.D;
+    line = u - chunk * g.D;
+    j0 = chunk * g.chc * g.D + line;
+    step = g.D;
+    count = g.chc;
+  } else {
+    const uint32_t v = u - g.D * g.NC;
+    line = g.D + v / g.NC;
+    chunk = v - (v / g.NC) * g.NC;
+  }
+  typename P::Acc acc, tmp, p;
+  P::zero(acc);
+  auto add_bucket_acc = [&](size_t gb) {
+    for (uint32_t q = cscan[gb]; q < cscan[gb + 1]; q++) {
+      P::load(p, accs + (size_t)q * XW);
+      P::add(tmp, acc, p);
+      acc = tmp;
+    }
+  };
+  // the chunk ranges of the next bucket are requested one step ahead
+  uint32_t qa = 0, qb = 0;
+  auto range = [&](uint32_t i, uint32_t& a, uint32_t& b) {
+    const uint32_t j = j0 + i * step;
+    a = b = 0;
+    if (i < count && j >= 1) {
+      const size_t gb = (size_t)kw * g.L + (j - 1);
+      a = cscan[gb];
+      b = cscan[gb + 1];
+    }
+  };
+  range(0, qa, qb);
+#pragma unroll 1
+  for (uint32_t i = 0; i < count; i++) {
+    uint32_t na, nb;
+    range(i + 1, na, nb);
+    for (uint32_t q = qa; q < qb; q++) {
+      P::load(p, accs + (size_t)q * XW);
+      P::add(tmp, acc, p);
+      acc = tmp;
+    }
+    qa = na;
+    qb = nb;
+  }
+  if (!col && line == g.H / 2 && chunk == 0) {
+    for (int twice = 0; twice < 2; twice++) add_bucket_acc((size_t)kw * g.L + (g.L - 1));
+  }
+  P::store(part + ((size_t)(prob * g.H + line) * g.NC + chunk) * XW, acc);
+}
+
+// n neutral accumulators (the C inputs of the first weighted level).  Not a memset: the twisted-Edwards identity is
+// (0, 1, 1, 0), only the XYZZ infinity is an all-zero record.
+template <class P>
+__global__ void __launch_bounds__(256) k_fill_neutral(uint32_t* out, uint32_t n) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  typename P::Acc z;
+  P::zero(z);
+  P::store(out + (size_t)t * P::ACC_WORDS, z);
+}
+
 // out[i] = in[2 i] + in[2 i + 1], one thread per addition
 template <class P>
 __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_pairsum(uint32_t* out, const uint32_t* in, uint32_t n_out) {
