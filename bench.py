@@ -232,7 +232,7 @@ def main():
 def pmc_traffic(key):
     """HBM bytes per launch (k_coarse) / per MSM (sort, k_batch_add) from the rocprofv3 PMC passes committed under
     profiles/ (FETCH_SIZE and WRITE_SIZE, separate passes; see profiles/README.md for the corrections applied)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)[key]["hbm_bytes"]

@@ -387,9 +387,10 @@ class Engine : public IEngine {
     msmz_opts opt;
     memset(&opt, 0, sizeof(opt));
     if (o) opt = *o;
-    // glv < 0: the engine's choice.  The split halves the windows but doubles the point set: ahead up to 2^20 points
-    // (4.0 vs 4.1 ms), behind from 2^21 on (7.1 vs 6.7 ms; 25.1 vs 22.3 ms at 2^23) -- profiles/r02_sweep.json.
-    if (opt.glv < 0) opt.glv = (!TE && Fr::HAS_GLV && pit->second.has_endo && n < (1ull << 21)) ? 1 : 0;
+    // glv < 0: the engine's choice.  The split halves the windows but doubles the point set (index bits, gathers, tree
+    // depth); since the two-dimensional bucket reduction made the reduction cheap per window it is only ahead on the
+    // smallest inputs (profiles/r03_sweep.json: 2^14 0.85 vs 0.88 ms, 2^16 1.11 vs 1.07, 2^20 3.87 vs 3.64, 2^23 23.5 vs 20.5).
+    if (opt.glv < 0) opt.glv = (!TE && Fr::HAS_GLV && pit->second.has_endo && n < (1ull << 15)) ? 1 : 0;
     MSMZ_HIP(hipSetDevice(device_));
 
     const uint32_t* d_scalars = nullptr;
@@ -676,14 +677,17 @@ class Engine : public IEngine {
     return fb;
   }
 
-  // Default window size.  Large inputs (M >= 2^19) are throughput-bound: c = log2 M - 3 capped at 17, stepped
+  // Default window size.  Large inputs (M >= 2^18: profiles/r03_sweep.json) are throughput-bound: c = log2 M - 3 capped at 17, stepped
   // down while the top window would be nearly empty.  Smaller inputs are latency-bound -- every tree round costs
   // ~75 us whatever its size and the number of rounds is log2 of the LONGEST bucket, which usually sits in a
   // partly filled top window -- so they pick the c that minimizes a small cost model fitted to this GPU
   // (ms: rounds * 0.075 + additions / 4.5e6 + reduction levels * 0.065 + buckets * 0.8e-6).
   int choose_window(bool glv, uint32_t M, int b, bool tree_rounds) const {
     int c = default_window(M);
-    if (M >= (1u << 19) || no_window_model_) {
+    if (M >= (1u << 18) || no_window_model_) {
+      // measured optimum of the batched-affine path from 2^18 entries per window on (profiles/r03_sweep.json): 17 without
+      // GLV (2^18: 1.60 ms against 1.83 at c = 15), 16 with it (128-bit halves = 8 windows exactly)
+      if (tree_rounds && !no_window_model_) c = glv ? 16 : 17;
       for (int tries = 0; tries < 3 && c > 4; tries++) {
         const int K0 = (b + 1 + c - 1) / c;
         const int top_bits = b + 1 - (K0 - 1) * c;

@@ -43,7 +43,8 @@ res = {
     "sort": dict(entry(sort_kernels, reps), per="MSM"),
     "k_batch_add": dict(entry(["k_batch_add"], reps), per="MSM (all tree rounds)"),
     "k_plan": dict(entry(["k_plan_count", "k_plan_emit"], reps), per="MSM"),
-    "reduce": dict(entry(["k_reduce_first", "k_reduce_quad", "k_reduce_quad16", "k_reduce_tail"], reps), per="MSM"),
+    "reduce": dict(entry(["k_reduce2d_partial", "k_reduce2d_partial_acc", "k_pairsum", "k_pairsum_x4", "k_fill_neutral", "k_reduce_first",
+                          "k_reduce_quad", "k_reduce_quad16", "k_reduce_tail"], reps), per="MSM"),
 }
 json.dump(res, open(out, "w"), indent=1)
 print(open(out).read())

@@ -6,7 +6,7 @@ Per size (BLS12-377 G1, msmUnsafe, reference protocol: warm-up, then `runs` MSMs
 ms per MSM, Mpoint-adds/s, the window the engine chose (c, K), the bucket-scatter kernel's fraction of the 8 TB/s HBM
 peak (32 n + 4 E algorithmic bytes over its HIP-event time), the same for the whole sort, and the tree rounds'
 field-multiplication rate against the measured 72 Gmodmul/s.  GLV on (the reference's default) and off.
-Window sweep: for n in 14, 16, 18, 20 every c in [n-5, n+1] capped at 21 (evaluate-msm-377.ts sweeps c around n-1 for
+Window sweep: for n in 14 .. 22 every c in [n-6, n] within [7, 19] (evaluate-msm-377.ts sweeps c around n-1 for
 its CPU cost model; here the optimum sits near n-3).
 """
 import json, os, statistics, sys, time
@@ -59,8 +59,8 @@ for lg in range(14, 25):
         r = evaluate(1 << lg, {"glv": glv}, 8 if lg <= 22 else 4)
         res["sizes"].append(r)
         print(json.dumps(r), flush=True)
-for lg in (14, 16, 18, 20):
-    for c in range(max(lg - 5, 6), min(lg + 1, 21) + 1):
+for lg in range(14, 23):
+    for c in range(max(lg - 6, 7), min(lg, 19) + 1):
         for glv in (1, 0):
             r = evaluate(1 << lg, {"glv": glv, "c": c}, 5)
             res["window_sweep"].append({k: r[k] for k in ("log2n", "glv", "c", "K", "rounds", "ms_per_msm", "stdev_ms")})
