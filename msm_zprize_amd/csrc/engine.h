@@ -609,6 +609,7 @@ class Engine : public IEngine {
     uint32_t n, M, L, nb, nblocks;
     int c, K, b;
     int Keff, spread;           // bucket windows incl. the top window's 2^spread sub-windows
+    int fold_shift = 0, fold_rows = 0;   // ... or the top window folded into its own bucket set (SortGeom)
     bool glv, timing;
     uint32_t max_bucket = 0, n_entries = 0;
     uint32_t endo_delta = 0;    // GLV over a prefix of a set: half-1 entry i reads point record pts_n + i = (n + i) + endo_delta
@@ -632,8 +633,9 @@ class Engine : public IEngine {
   struct Geometry {
     int c, K, t_top, spread, Keff;
     uint32_t L;
+    int fold_shift = 0, fold_rows = 0;   // thin top window folded into its own bucket set (sort_kernels.h SortGeom)
   };
-  Geometry geometry(int c, bool glv, uint32_t M, int b) const {
+  Geometry geometry(int c, bool glv, uint32_t M, int b, bool allow_fold = false) const {
     Geometry g;
     g.c = c;
     g.K = (b + 1 + c - 1) / c;                              // msm-batched-affine.ts:96
@@ -651,7 +653,22 @@ class Engine : public IEngine {
       if (g.t_top < 1) g.t_top = 1;
     }
     g.spread = 0;
-    if (!no_spread_ && g.K > 1 && g.t_top <= c - 2) {
+    {
+      // a thin top window whose digit fits the COLUMN index of the two-dimensional reduction (l < D = 2^b2) is folded:
+      // 2^(c-1-b2) copies of the digit's range fill the set's buckets as evenly as any other window's.  The bound on
+      // the digit is the hard one (largest scalar; for GLV halves the bit length the windows were sized for).
+      const int b2 = (c - 1) - (c - 1 + 1) / 2;                       // low bits of Split2d
+      const int t_bound = glv ? b + 1 - pos : g.t_top;
+      // (only where the two-level sort applies: the fallback sort numbers buckets by digit alone)
+      const uint32_t ncb0 = g.L >> fine_bits(c, M);
+      const bool sort2 = !force_atomic_sort_ && M <= (1u << 24) && ncb0 <= (uint32_t)COARSE_MAX_BINS &&
+                         (uint64_t)g.K * ncb0 <= (uint64_t)SORT_MAX_BINS;
+      if (allow_fold && !no_fold_ && sort2 && g.K > 1 && g.t_top <= c - 2 && b2 >= 1 && t_bound <= b2) {
+        g.fold_shift = b2;
+        g.fold_rows = c - 1 - b2;
+      }
+    }
+    if (g.fold_shift == 0 && !no_spread_ && g.K > 1 && g.t_top <= c - 2) {
       g.spread = c - 1 - g.t_top;
       if (g.spread > 3) g.spread = 3;
       const int ib = ceil_log2_u64(M < 2 ? 2 : M);
@@ -719,7 +736,7 @@ class Engine : public IEngine {
   }
 
   int make_plan(Plan& pl, uint64_t n64, bool glv, const msmz_opts& opt, uint32_t pts_n, bool tree_rounds = true,
-                int extra_bits = 0) {
+                int extra_bits = 0, bool allow_fold = false) {
     pl.n = (uint32_t)n64;
     pl.glv = glv;
     pl.M = glv ? 2 * pl.n : pl.n;
@@ -737,10 +754,12 @@ class Engine : public IEngine {
     pl.c = opt.c > 0 ? opt.c : choose_window(glv, pl.M, pl.b, tree_rounds);
     if (pl.c < 2) pl.c = 2;
     if (pl.c > 24) pl.c = 24;
-    const Geometry g = geometry(pl.c, glv, pl.M, pl.b);
+    const Geometry g = geometry(pl.c, glv, pl.M, pl.b, allow_fold);
     pl.K = g.K;
     pl.L = g.L;
     pl.spread = g.spread;
+    pl.fold_shift = g.fold_shift;
+    pl.fold_rows = g.fold_rows;
     pl.Keff = g.Keff;
     const uint64_t nb64 = (uint64_t)pl.Keff * pl.L;
     if (nb64 + 1 >= (1ull << 31) || (uint64_t)pl.K * pl.M >= (1ull << 32) || pl.Keff > kMaxWindows) return MSMZ_ERR_ARG;
@@ -777,7 +796,7 @@ class Engine : public IEngine {
       uint32_t* d_counts = counts_.as<uint32_t>();
       uint32_t* d_cursor = d_counts + nbins;
       MSMZ_HIP(hipMemsetAsync(d_counts, 0, (size_t)2 * nbins * 4, stream_));
-      SortGeom g{n, M, c, K, fb, pl.spread, idx_bits, ncb};
+      SortGeom g{n, M, c, K, fb, pl.spread, idx_bits, ncb, pl.fold_shift, pl.fold_rows};
       mark(pl);  // 0
       const uint32_t per_tile = pl.glv ? COARSE_TILE / 2 : COARSE_TILE;   // scalars per workgroup (k_hist and k_coarse)
       const uint32_t tiles = (n + per_tile - 1) / per_tile;
@@ -821,6 +840,7 @@ class Engine : public IEngine {
     } else {
       // fallback (window sizes whose coarse bins do not fit the LDS staging): digits materialized, one global
       // atomic per entry
+      if (pl.fold_shift != 0) return MSMZ_ERR_ARG;   // (make_plan only folds when the two-level sort applies)
       if ((st = digits_.ensure((size_t)K * M * 4))) return st;
       if ((st = counts_.ensure(((size_t)nb + 1) * 4))) return st;
       if ((st = cursor_.ensure((size_t)nb * 4))) return st;
@@ -1042,6 +1062,7 @@ class Engine : public IEngine {
     auto add_results = [&](int k, int which) {
       // bucket sets of window k: kw = k below the top window, K-1 .. Keff-1 (its sub-windows) for the top one
       const int lo = k, hi = (k == pl.K - 1) ? pl.Keff - 1 : k;
+      if (which == 0 && k == pl.K - 1 && pl.fold_shift != 0) return;   // folded top window: its rows are copies, not weights
       for (int kw = lo; kw <= hi; kw++) {
         host64_.load_pt(w, h_final_ + (size_t)(kMaxWindows + 2 * kw + which) * XW);
         host64_.add_pt(t, acc, w);
@@ -1106,7 +1127,8 @@ class Engine : public IEngine {
     const bool glv = opt.glv != 0;
     if (glv && (!Fr::HAS_GLV || !pts.has_endo)) return MSMZ_ERR_UNSUPPORTED;
     Plan pl;
-    int st = make_plan(pl, n64, glv, opt, (uint32_t)pts.n, true, extra_bits);
+    const bool want_2d = opt.reserved[0] != 1 && reduce2d_;
+    int st = make_plan(pl, n64, glv, opt, (uint32_t)pts.n, true, extra_bits, want_2d);
     if (st) return st;
     // location words hold a record index in 30 bits
     if ((uint64_t)pl.K * pl.M >= (1ull << 30)) return MSMZ_ERR_ARG;
@@ -1533,6 +1555,7 @@ class Engine : public IEngine {
   uint32_t quad16_max_groups_ = (uint32_t)env_int("MSMZ_QUAD16", 8192);   // levels with at most this many groups use k_reduce_quad16
   Host64<F> host64_;
   bool no_spread_ = env_int("MSMZ_NO_SPREAD", 0) != 0;
+  bool no_fold_ = env_int("MSMZ_NO_FOLD", 0) != 0;
   bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
   bool reduce2d_ = env_int("MSMZ_REDUCE2D", 1) != 0;          // two-dimensional bucket reduction (reduce2d_kernels.h); 0 = the grouped running sums

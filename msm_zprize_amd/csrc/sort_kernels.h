@@ -35,7 +35,18 @@ struct SortGeom {
   uint32_t M;          // entries per window: n, or 2 n with GLV (entry n + i = endomorphism half of scalar i)
   int c, K, fb, spread, idx_bits;
   uint32_t ncb;        // coarse bins per bucket set = L >> fb
+  // A THIN top window (its digit has only a few significant bits) can be FOLDED into its own bucket set instead of
+  // spread over sub-windows: bucket weight j = (entry mod 2^fold_rows) * 2^fold_shift + l, i.e. the L buckets of the set
+  // hold 2^fold_rows copies ("rows") of the digit's small range, and the two-dimensional reduction's COLUMN sums are
+  // exactly the per-digit sums (the row result of that set is not used).  fold_shift = 0: not folded.
+  int fold_shift, fold_rows;
 };
+
+// bucket index (weight - 1) of digit l of window k inside its bucket set
+__device__ __forceinline__ uint32_t bucket_index(const SortGeom& g, int k, uint32_t l, uint32_t entry) {
+  if (g.fold_shift != 0 && k == g.K - 1) return ((entry & ((1u << g.fold_rows) - 1u)) << g.fold_shift) + l - 1u;
+  return l - 1u;
+}
 
 // The (half-)scalars of one input scalar as little-endian words.  Windows are sliced with a word index that is the
 // same for every lane (the window loop is wave-uniform), so a window costs two register moves out of a uniform
@@ -122,7 +133,7 @@ struct DigitStream {
 __device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_t l, uint32_t entry) {
   uint32_t kw = (uint32_t)k;
   if (k == g.K - 1) kw += entry & ((1u << g.spread) - 1u);
-  return kw * g.ncb + ((l - 1) >> g.fb);
+  return kw * g.ncb + (bucket_index(g, k, l, entry) >> g.fb);
 }
 
 // ------------------------------------------------------------------------------------------------ histogram
@@ -293,7 +304,7 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
         const uint32_t l = ds[s].next(h, k, g.c, L, ng);
         if (l != 0) {
           const uint32_t entry = (uint32_t)h * g.n + idx[s];
-          const uint32_t bi = l - 1;
+          const uint32_t bi = bucket_index(g, k, l, entry);
           const uint32_t bin = (entry & smask) * g.ncb + (bi >> g.fb);
           const uint32_t rank = atomicAdd(&cur_k[bin], 1u);
           const uint32_t pos = off_k[bin] - wbase + rank;

@@ -429,3 +429,24 @@ def test_download_ranges_cannot_wrap(curves):
     assert lib().msmz_download_scalars(curve._ctx, sc.handle, 7, 2, buf) == 1
     assert lib().msmz_download_scalars(curve._ctx, sc.handle, 7, 1, buf) == 0
     pts.free(); sc.free()
+
+
+@pytest.mark.parametrize("label,glv,c", [("bls12-377", 0, 14), ("bls12-377", 0, 18), ("bls12-377", 0, 11), ("bls12-377", 1, 9),
+                                         ("pallas", 0, 17), ("pallas", 0, 15), ("bls12-381", 0, 16)])
+def test_thin_top_window_is_folded(curves, label, glv, c):
+    """A user-chosen window size whose TOP window has only 1-2 significant bits: the engine folds that window into its
+    own bucket set (copies of the digit's small range instead of a handful of long buckets; the two-dimensional
+    reduction's column sums are the per-digit sums).  Same result as the oracle, safe and unsafe, and far fewer tree
+    rounds than the longest bucket of the unfolded layout would need."""
+    curve = curves(label)
+    for n, seed in ((300, 31), (4096, 32)):
+        pts = curve.Parallel.randomPointsFast(n, seed)
+        sc = curve.Parallel.randomScalars(n, seed + 100)
+        want = _oracle(label, curve.Scalar.toBigints(sc), curve.Affine.toBigints(pts))
+        out = curve.Parallel.msmUnsafe(sc, pts, n, True, {"glv": glv, "c": c})
+        assert out["result"] == want, (n, "unsafe")
+        assert curve.Parallel.msm(sc, pts, n, False, {"glv": glv, "c": c})["result"] == want, (n, "safe")
+        if n == 4096:
+            # unfolded, the top window's <= 4 digit values x <= 8 sub-windows would hold >= n / 32 entries per bucket
+            assert out["stats"].max_bucket < n // 32, out["stats"].max_bucket
+        pts.free(); sc.free()
