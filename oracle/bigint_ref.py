@@ -412,3 +412,41 @@ def signed_digits(s: int, c: int, K: int):
             carry = 0
         out.append((l, carry))
     return out
+
+
+# ------------------------------------------------------------------------------------------ bucket reduction
+def reduce_buckets_running_sum(curve, buckets):
+    """sum_{l=1..L} l * B_l by the reference's running sum (msm-batched-affine.ts:544-571 reduceBucketsColumnProjective,
+    msm-basic.ts:192-223): buckets[l - 1] = B_l in the curve's projective / extended form (curve.zero = empty)."""
+    running, total = curve.zero, curve.zero
+    for B in reversed(buckets):
+        running = curve.add(running, B)
+        total = curve.add(total, running)
+    return total
+
+
+def reduce_buckets_2d(curve, buckets, c):
+    """The same sum the way the HIP engine forms it (msm_zprize_amd/csrc/reduce2d_kernels.h): the weight j = l is split
+    j = h * D + d with H = 2^ceil((c-1)/2) rows and D = L / H columns,
+        sum_j j E_j = D * sum_h h R_h + sum_d d C_d,   R_h = sum_d E[h D + d],  C_d = sum_h E[h D + d],
+    the bucket of weight L = H * D is added twice into row H / 2, and the factor D is applied as b = log2 D doublings
+    (the host's Horner pass adds the row result b bit positions above the column result).  Returns the window sum."""
+    L = 1 << (c - 1)
+    assert len(buckets) == L
+    a = (c - 1 + 1) // 2
+    b = c - 1 - a
+    H, D = 1 << a, 1 << b
+    E = [curve.zero] + list(buckets[:L - 1])           # E[j] = bucket of weight j, j in [0, L)
+    rows = [curve.zero] * H
+    cols = [curve.zero] * D
+    for j in range(1, L):
+        h, d = divmod(j, D)
+        rows[h] = curve.add(rows[h], E[j])
+        cols[d] = curve.add(cols[d], E[j])
+    for _ in range(2):
+        rows[H // 2] = curve.add(rows[H // 2], buckets[L - 1])
+    weighted = lambda xs: reduce_buckets_running_sum(curve, xs[1:]) if len(xs) > 1 else curve.zero   # sum_i i * xs[i]
+    A, Bc = weighted(rows), weighted(cols)
+    for _ in range(b):
+        A = curve.double(A)
+    return curve.add(A, Bc)

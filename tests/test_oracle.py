@@ -165,3 +165,29 @@ def test_sharded_c_oracle_equals_plain():
         want = c_oracle.msm_bytes(c, sb, pb, n, None, 4)[0]
         for shards in (1, 2, 5, 700, 900):
             assert c_oracle.msm_bytes_sharded(c, sb, pb, n, shards, 4)[0] == want, (c["label"], shards)
+
+
+@pytest.mark.parametrize("c", [2, 3, 4, 5, 6, 9])
+@pytest.mark.parametrize("label", ["bls12-377", "pallas", "ed-on-bls12-377"])
+def test_bucket_reduction_2d_equals_running_sum(label, c):
+    """The engine's two-dimensional bucket reduction (reduce2d_kernels.h: row / column sums + two half-length weighted
+    sums, the factor D applied as doublings) is the same group element as the reference's running sum
+    (msm-batched-affine.ts:544-571) -- on random buckets incl. empty ones, for even and odd splits of the index bits."""
+    params = P.CURVES[label]
+    te = params["kind"] != "weierstrass"
+    C = B.TwistedEdwards(params) if te else B.ProjectiveWeierstrass(params)
+    rng = random.Random(100 * c + len(label))
+    g = C.one if hasattr(C, "one") else None
+    if g is None:
+        gx, gy = params["generator"]["x"], params["generator"]["y"]
+        g = C.from_affine((gx, gy)) if te else C.from_affine((gx, gy, False))
+    L = 1 << (c - 1)
+    buckets = [C.zero if rng.random() < 0.2 else C.scale(rng.randrange(1, 1 << 32), g) for _ in range(L)]
+    want = B.reduce_buckets_running_sum(C, buckets)
+    got = B.reduce_buckets_2d(C, buckets, c)
+    assert C.is_equal(got, want)
+    # and both are sum l * B_l
+    direct = C.zero
+    for l, bk in enumerate(buckets, start=1):
+        direct = C.add(direct, C.scale(l, bk))
+    assert C.is_equal(want, direct)
