@@ -199,7 +199,7 @@ class Engine : public IEngine {
   ~Engine() override {
     (void)hipSetDevice(device_);
     for (auto& kv : handles_) (void)hipFree(kv.second.dev);
-    for (DevBuf* b : {&f2desc_, &tilecnt_, &final_, &desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+    for (DevBuf* b : {&bsum_, &f2desc_, &tilecnt_, &final_, &desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
                       &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
       b->release();
     if (h_meta_) (void)hipHostFree(h_meta_);
@@ -1007,7 +1007,7 @@ class Engine : public IEngine {
   // basic = true: the buckets are sums of partial accumulators (msmBasic path: slots_ + rscan_), else the affine bucket
   // sums of the tree rounds (bfin_)
   template <class P>
-  int reduce_2d(const Plan& pl, const uint32_t* d_points, bool basic = false) {
+  int reduce_2d(const Plan& pl, const uint32_t* d_points, bool basic = false, bool summed = false) {
     const Split2d sp = split_2d(pl);
     R2Geom g;
     g.L = pl.L;
@@ -1023,7 +1023,10 @@ class Engine : public IEngine {
     // ping-pong between red_[0] and red_[2] (rows of the level machinery); C inputs of the first level = infinity
     if ((st = red_[0].ensure((size_t)total * XW * 4))) return st;
     if ((st = red_[2].ensure((size_t)total * XW * 4))) return st;
-    if (basic) {
+    if (basic && summed) {   // one accumulator per bucket in bsum_ (k_bucket_sums)
+      hipLaunchKernelGGL((k_reduce2d_partial_acc<P>), dim3((total + 127) / 128), dim3(128), 0, stream_,
+                         red_[0].as<uint32_t>(), bsum_.as<uint32_t>(), (const uint32_t*)nullptr, g, total);
+    } else if (basic) {
       hipLaunchKernelGGL((k_reduce2d_partial_acc<P>), dim3((total + 127) / 128), dim3(128), 0, stream_,
                          red_[0].as<uint32_t>(), slots_.as<uint32_t>(), rscan_.as<uint32_t>(), g, total);
     } else {
@@ -1269,12 +1272,17 @@ class Engine : public IEngine {
     }
     const int ev_acc_end = pl.ei;
     mark(pl);
-    // two-dimensional reduction when a bucket is (nearly always) ONE partial accumulator: every bucket is visited twice,
-    // so buckets of several chunks (large inputs: Pallas 2^22 has 4, ed-on-bls12-377 2^24 has 8) are cheaper in the
-    // grouped running sums, which read them once (measured: 1.21 vs 0.87 ms and 2.75 vs 1.79 ms)
-    basic_2d_ = reduce2d_ && pl.L >= 2 && (uint64_t)n_chunks * 2 <= (uint64_t)nb * 3;
+    basic_2d_ = reduce2d_ && pl.L >= 2;
     if (basic_2d_) {
-      if ((st = reduce_2d<P>(pl, d_points, true))) return st;
+      // every bucket is visited twice: buckets of several chunk accumulators (large inputs: Pallas 2^22 has 4,
+      // ed-on-bls12-377 2^24 has 8) are first summed into one accumulator each, in bucket order
+      const bool summed = (uint64_t)n_chunks * 2 > (uint64_t)nb * 3 && !no_bucket_sums_;
+      if (summed) {
+        if ((st = bsum_.ensure((size_t)nb * AW * 4))) return st;
+        hipLaunchKernelGGL((k_bucket_sums<P>), dim3((nb + 127) / 128), dim3(128), 0, stream_, bsum_.as<uint32_t>(),
+                           slots_.as<uint32_t>(), rscan_.as<uint32_t>(), nb);
+      }
+      if ((st = reduce_2d<P>(pl, d_points, true, summed))) return st;
       const int ev_red_end2 = pl.ei;
       mark(pl);
       if ((st = fetch_window_sums<P>(pl, 0, 2u * (uint32_t)pl.Keff))) return st;
@@ -1556,6 +1564,7 @@ class Engine : public IEngine {
   Host64<F> host64_;
   bool no_spread_ = env_int("MSMZ_NO_SPREAD", 0) != 0;
   bool no_fold_ = env_int("MSMZ_NO_FOLD", 0) != 0;
+  bool no_bucket_sums_ = env_int("MSMZ_NO_BUCKET_SUMS", 0) != 0;
   bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
   bool reduce2d_ = env_int("MSMZ_REDUCE2D", 1) != 0;          // two-dimensional bucket reduction (reduce2d_kernels.h); 0 = the grouped running sums
@@ -1565,7 +1574,7 @@ class Engine : public IEngine {
   int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
   int retries_ = 0;            // MSMs redone with the proven GLV bound (test hook reads it)
   int glv_bits_assumed_ = 0;   // test hook (msmz_test_set_glv_bits): assumed bit length of a GLV half; 0 = GLV_BITS - 1
-  DevBuf f2desc_, tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  DevBuf bsum_, f2desc_, tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};
   int basic_ev_[4] = {};

@@ -55,6 +55,7 @@
                                                 uint32_t);                                                       \
   PFX template __global__ void k_pairsum<P>(uint32_t*, const uint32_t*, uint32_t);                               \
   PFX template __global__ void k_fill_neutral<P>(uint32_t*, uint32_t);                                           \
+  PFX template __global__ void k_bucket_sums<P>(uint32_t*, const uint32_t*, const uint32_t*, uint32_t);          \
   PFX template __global__ void k_reduce2d_partial_acc<P>(uint32_t*, const uint32_t*, const uint32_t*, R2Geom, uint32_t); \
   PFX template __global__ void k_pairsum_x4<P>(uint32_t*, const uint32_t*, uint32_t);                            \
   PFX template __global__ void k_reduce_next<P>(uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,          \

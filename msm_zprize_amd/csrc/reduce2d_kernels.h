@@ -159,21 +159,23 @@ __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce2d_partial_acc(u
   typename P::Acc acc, tmp, p;
   P::zero(acc);
   auto add_bucket_acc = [&](size_t gb) {
-    for (uint32_t q = cscan[gb]; q < cscan[gb + 1]; q++) {
+    const uint32_t q0 = cscan ? cscan[gb] : (uint32_t)gb, q1 = cscan ? cscan[gb + 1] : (uint32_t)gb + 1u;
+    for (uint32_t q = q0; q < q1; q++) {
       P::load(p, accs + (size_t)q * XW);
       P::add(tmp, acc, p);
       acc = tmp;
     }
   };
-  // the chunk ranges of the next bucket are requested one step ahead
+  // the chunk ranges of the next bucket are requested one step ahead (cscan == nullptr: accs holds ONE accumulator
+  // per bucket, in bucket order -- the sums k_bucket_sums formed)
   uint32_t qa = 0, qb = 0;
   auto range = [&](uint32_t i, uint32_t& a, uint32_t& b) {
     const uint32_t j = j0 + i * step;
     a = b = 0;
     if (i < count && j >= 1) {
       const size_t gb = (size_t)kw * g.L + (j - 1);
-      a = cscan[gb];
-      b = cscan[gb + 1];
+      a = cscan ? cscan[gb] : (uint32_t)gb;
+      b = cscan ? cscan[gb + 1] : (uint32_t)gb + 1u;
     }
   };
   range(0, qa, qb);
@@ -193,6 +195,28 @@ __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce2d_partial_acc(u
     for (int twice = 0; twice < 2; twice++) add_bucket_acc((size_t)kw * g.L + (g.L - 1));
   }
   P::store(part + ((size_t)(prob * g.H + line) * g.NC + chunk) * XW, acc);
+}
+
+// Buckets of several partial accumulators (large msmBasic inputs): one accumulator per bucket, in bucket order, so that
+// the two visits of the two-dimensional reduction read each bucket ONCE each instead of all its chunks twice.
+template <class P>
+__global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_bucket_sums(uint32_t* out, const uint32_t* accs, const uint32_t* cscan,
+                                                                      uint32_t nb) {
+  constexpr int XW = P::ACC_WORDS;
+  const uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gb >= nb) return;
+  typename P::Acc acc, tmp, p;
+  P::zero(acc);
+  const uint32_t q0 = cscan[gb], q1 = cscan[gb + 1];
+  if (q1 > q0) {
+    P::load(acc, accs + (size_t)q0 * XW);
+    for (uint32_t q = q0 + 1; q < q1; q++) {
+      P::load(p, accs + (size_t)q * XW);
+      P::add(tmp, acc, p);
+      acc = tmp;
+    }
+  }
+  P::store(out + (size_t)gb * XW, acc);
 }
 
 // n neutral accumulators (the C inputs of the first weighted level).  Not a memset: the twisted-Edwards identity is
