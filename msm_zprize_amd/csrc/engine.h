@@ -174,8 +174,13 @@ class Engine : public IEngine {
 
   // dynamic LDS the sort kernels may be launched with (sort_phase never asks for more: SORT_MAX_BINS caps nbins)
   static constexpr size_t kFineLds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
-  static constexpr size_t kCoarseLdsMax = (size_t)3 * SORT_MAX_BINS * 4;
+  static constexpr size_t kCoarseLdsMax = (size_t)2 * SORT_MAX_BINS * 4;
   static constexpr size_t kHistLdsMax = (size_t)SORT_MAX_BINS * 4;
+#ifdef MSMZ_TRACE
+  static constexpr size_t kTraceBytes = 128;   // per workgroup, behind the buffers the sort kernels receive (tools/wg_timeline.py)
+#else
+  static constexpr size_t kTraceBytes = 0;
+#endif
 
   int raise_lds_limit(const void* fn, const char* name, size_t dyn_max) {
     hipFuncAttributes fa;
@@ -199,7 +204,7 @@ class Engine : public IEngine {
   ~Engine() override {
     (void)hipSetDevice(device_);
     for (auto& kv : handles_) (void)hipFree(kv.second.dev);
-    for (DevBuf* b : {&bsum_, &f2desc_, &tilecnt_, &final_, &desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
+    for (DevBuf* b : {&bsum_, &f2desc_, &tilecnt_, &tileoff_, &final_, &desc_, &bfin_, &packed_, &bins_, &digits_, &counts_, &off_, &cursor_, &refs_, &rscan_, &partials_, &slots_, &red_[0], &red_[1],
                       &red_[2], &red_[3], &meta_, &stage_, &gen_table_})
       b->release();
     if (h_meta_) (void)hipHostFree(h_meta_);
@@ -791,23 +796,23 @@ class Engine : public IEngine {
     const uint32_t n_half = pl.glv ? n : 0xffffffffu;
     if (sort2) {
       if ((st = packed_.ensure((size_t)K * M * 4))) return st;
-      if ((st = bins_.ensure(((size_t)nbins + 1) * 4))) return st;
-      if ((st = counts_.ensure((size_t)2 * nbins * 4))) return st;   // [counts | cursors]
+      if ((st = bins_.ensure(((size_t)nbins + 2) * 4 + kTraceBytes * nbins))) return st;
+      if ((st = counts_.ensure((size_t)nbins * 4))) return st;
       uint32_t* d_counts = counts_.as<uint32_t>();
-      uint32_t* d_cursor = d_counts + nbins;
-      MSMZ_HIP(hipMemsetAsync(d_counts, 0, (size_t)2 * nbins * 4, stream_));
+      MSMZ_HIP(hipMemsetAsync(d_counts, 0, (size_t)nbins * 4, stream_));
       SortGeom g{n, M, c, K, fb, pl.spread, idx_bits, ncb, pl.fold_shift, pl.fold_rows};
       mark(pl);  // 0
       const uint32_t per_tile = pl.glv ? COARSE_TILE / 2 : COARSE_TILE;   // scalars per workgroup (k_hist and k_coarse)
       const uint32_t tiles = (n + per_tile - 1) / per_tile;
       if ((st = tilecnt_.ensure((size_t)tiles * nbins * 2))) return st;
+      if ((st = tileoff_.ensure((size_t)tiles * nbins * 4 + kTraceBytes * tiles))) return st;   // the tiles' runs inside the bins
       if (pl.glv) {
         if constexpr (Fr::HAS_GLV)
           hipLaunchKernelGGL((k_hist<Fr, true>), dim3(tiles), dim3(COARSE_T), (size_t)nbins * 4, stream_, d_counts,
-                             tilecnt_.as<uint16_t>(), d_meta, d_scalars, g, nbins);
+                             tilecnt_.as<uint16_t>(), tileoff_.as<uint32_t>(), d_meta, d_scalars, g, nbins);
       } else {
         hipLaunchKernelGGL((k_hist<Fr, false>), dim3(tiles), dim3(COARSE_T), (size_t)nbins * 4, stream_, d_counts,
-                           tilecnt_.as<uint16_t>(), d_meta, d_scalars, g, nbins);
+                           tilecnt_.as<uint16_t>(), tileoff_.as<uint32_t>(), d_meta, d_scalars, g, nbins);
       }
       mark(pl);  // 1
       MSMZ_HIP(hipGetLastError());
@@ -817,15 +822,15 @@ class Engine : public IEngine {
       MSMZ_HIP(hipGetLastError());
       {
         const uint32_t grid = tiles;
-        const size_t lds = (size_t)3 * nbins * 4;   // <= kCoarseLdsMax (nbins <= SORT_MAX_BINS): the limit init() raised
+        const size_t lds = (size_t)2 * nbins * 4;   // <= kCoarseLdsMax (nbins <= SORT_MAX_BINS): the limit init() raised
         if (pl.glv) {
           if constexpr (Fr::HAS_GLV) {
             hipLaunchKernelGGL((k_coarse<Fr, true>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
-                               d_cursor, bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
+                               tileoff_.as<uint32_t>(), bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
           }
         } else {
           hipLaunchKernelGGL((k_coarse<Fr, false>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
-                             d_cursor, bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
+                             tileoff_.as<uint32_t>(), bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
         }
       }
       pl.ev_coarse = pl.ei;
@@ -837,6 +842,22 @@ class Engine : public IEngine {
                            &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins, idx_bits, n_half,
                            pl.endo_delta);
       }
+#ifdef MSMZ_TRACE
+      if (const char* path = getenv("MSMZ_TRACE_OUT")) {   // development aid: workgroup time stamps of k_coarse / k_fine
+        MSMZ_HIP(hipStreamSynchronize(stream_));
+        const uint32_t trace_tiles = tiles;
+        std::vector<uint64_t> tc((size_t)trace_tiles * 16), tf((size_t)nbins * 16);
+        MSMZ_HIP(hipMemcpy(tc.data(), tileoff_.as<uint32_t>() + (size_t)tiles * nbins, tc.size() * 8, hipMemcpyDeviceToHost));
+        MSMZ_HIP(hipMemcpy(tf.data(), bins_.as<uint32_t>() + ((nbins + 2) & ~1u), tf.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(path, "wb")) {
+          const uint64_t hdr[2] = {trace_tiles, nbins};
+          fwrite(hdr, 8, 2, f);
+          fwrite(tc.data(), 8, tc.size(), f);
+          fwrite(tf.data(), 8, tf.size(), f);
+          fclose(f);
+        }
+      }
+#endif
     } else {
       // fallback (window sizes whose coarse bins do not fit the LDS staging): digits materialized, one global
       // atomic per entry
@@ -1574,7 +1595,7 @@ class Engine : public IEngine {
   int batch_b_override_ = env_int("MSMZ_BATCH_B", 0);
   int retries_ = 0;            // MSMs redone with the proven GLV bound (test hook reads it)
   int glv_bits_assumed_ = 0;   // test hook (msmz_test_set_glv_bits): assumed bit length of a GLV half; 0 = GLV_BITS - 1
-  DevBuf bsum_, f2desc_, tilecnt_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
+  DevBuf bsum_, f2desc_, tilecnt_, tileoff_, final_, desc_, bfin_, packed_, bins_, digits_, counts_, off_, cursor_, refs_, rscan_, partials_, slots_, red_[4], meta_, stage_, gen_table_;
   uint32_t h_round_pairs_[32] = {};
   uint32_t h_round_base_[32] = {};
   int basic_ev_[4] = {};

@@ -25,10 +25,29 @@ constexpr int COARSE_ITEMS = 2;                        // half-scalars (= entrie
 constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // entries per window staged by one workgroup
 constexpr int COARSE_MAX_BINS = 512;                   // bins per window (top window: incl. its sub-windows) the staging supports
 constexpr int SORT_MAX_BINS = 8192;                    // all windows: k_coarse keeps 3 words per bin in LDS (96 KB)
+constexpr int kMaxWindowsSort = 128;                   // windows a scalar can have (c >= 2)
 constexpr int FINE_MAX_BITS = 11;
 constexpr int FINE_T = 1024;
 constexpr int FINE_PER = 37;                           // entries a thread holds in registers
 constexpr int FINE_STAGE = FINE_T * FINE_PER;          // 37888 entries staged in LDS: 148 KB + 8 KB of counters (+ static) < 160 KB
+
+// Development aid (-DMSMZ_TRACE builds only): thread 0 of every workgroup stamps the 100 MHz wall clock into 16 slots
+// behind a buffer the kernel already receives; slot 15 = hardware id (which CU / XCD).  tools/wg_timeline.py reads them.
+#ifdef MSMZ_TRACE
+#define MSMZ_STAMP(tr, slot)                                                         \
+  do {                                                                               \
+    if (threadIdx.x == 0) (tr)[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64();   \
+  } while (0)
+#define MSMZ_STAMP_HW(tr)                                                                                     \
+  do {                                                                                                        \
+    if (threadIdx.x == 0)                                                                                     \
+      (tr)[(size_t)blockIdx.x * 16 + 15] =                                                                    \
+          (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+  } while (0)
+#else
+#define MSMZ_STAMP(tr, slot) do {} while (0)
+#define MSMZ_STAMP_HW(tr) do {} while (0)
+#endif
 
 struct SortGeom {
   uint32_t n;          // scalars
@@ -141,8 +160,8 @@ __device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_
 // bound: the host then repeats the MSM with one more bit), |= 4 when a scalar is not below the group order
 // (scalarsFromBytes' precondition, checked here instead of in a serial host loop).
 template <class Fr, bool GLV>
-__global__ void __launch_bounds__(COARSE_T) k_hist(uint32_t* counts, uint16_t* tile_counts, MsmMeta* meta, const uint32_t* scalars,
-                                              SortGeom g, uint32_t nbins) {
+__global__ void __launch_bounds__(COARSE_T, 8) k_hist(uint32_t* counts, uint16_t* tile_counts, uint32_t* tile_offs, MsmMeta* meta,
+                                                 const uint32_t* scalars, SortGeom g, uint32_t nbins) {
   extern __shared__ uint32_t s_hist[];
   constexpr int HALVES = GLV ? 2 : 1;
   constexpr int PER = COARSE_ITEMS / HALVES;   // scalars per thread: one workgroup = one tile of k_coarse
@@ -179,11 +198,27 @@ __global__ void __launch_bounds__(COARSE_T) k_hist(uint32_t* counts, uint16_t* t
     if (ds[it].overflows(g.K, g.c)) bad |= 2u;
   if (bad) atomicOr(&meta->error, bad);
   __syncthreads();
+  // The tile's run inside every bin is reserved HERE: the atomic that builds the global counts returns where the
+  // tile's entries start in the bin (the scatter kernel then needs no atomics: 512 tiles x 512 bins returning atomics on
+  // 512 addresses cost it ~7 us of its 41).  All of a thread's atomics are in flight together.
   uint16_t* row = tile_counts + (size_t)blockIdx.x * nbins;
-  for (uint32_t b = threadIdx.x; b < nbins; b += COARSE_T) {
-    const uint32_t v = s_hist[b];
-    row[b] = (uint16_t)v;             // <= COARSE_TILE entries of a tile fall into one bin
-    if (v) atomicAdd(&counts[b], v);
+  uint32_t* roff = tile_offs + (size_t)blockIdx.x * nbins;
+  constexpr int PB = SORT_MAX_BINS / COARSE_T;
+  uint32_t r[PB];
+#pragma unroll
+  for (int q = 0; q < PB; q++) {
+    const uint32_t b = (uint32_t)q * COARSE_T + threadIdx.x;
+    r[q] = 0;
+    if (b < nbins) {
+      const uint32_t v = s_hist[b];
+      row[b] = (uint16_t)v;             // <= COARSE_TILE entries of a tile fall into one bin
+      if (v) r[q] = atomicAdd(&counts[b], v);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PB; q++) {
+    const uint32_t b = (uint32_t)q * COARSE_T + threadIdx.x;
+    if (b < nbins) roff[b] = r[q];
   }
 }
 
@@ -230,28 +265,32 @@ static __global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* base, const 
 
 // ------------------------------------------------------------------------------------------------ coarse scatter
 // One tile = COARSE_TILE half-scalars (2048 scalars, or 1024 scalars with GLV) = the tile k_hist counted.
-//   setup    the tile's per-bin entry counts come from k_hist (2 bytes per bin); every bin's run is reserved in global
-//            memory with one atomic per bin -- all of them in flight together, ONE global-atomic latency per
-//            workgroup instead of one per window -- and a block scan turns the counts into staging offsets;
-//   windows  one by one: slice, rank the entries per bin (LDS atomics), stage them in LDS in bin order, write every
-//            bin's entries as one contiguous run.  Double-buffered staging: 2 barriers per window.
-// Algorithmic HBM bytes: 32 B read per scalar + 4 B written per entry.  Dynamic LDS: 3 * nbins words.
+//   setup    the tile's per-bin entry counts (2 bytes per bin) and the start of its run inside every bin (k_hist's
+//            returning atomics) are read back, a block scan turns the counts into staging offsets: no global atomics here;
+//   windows  one by one: slice, rank the entries per bin (one LDS atomic on a cursor that starts at the bin's staging
+//            offset), stage them in LDS in bin order, write every bin's entries as one contiguous run.  Double-buffered
+//            staging: 1 barrier per window.
+// Algorithmic HBM bytes: 32 B read per scalar + 4 B written per entry.  Dynamic LDS: 2 * nbins words.
 template <class Fr, bool GLV>
-__global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint32_t* bin_cursor, const uint32_t* bin_base,
-                                                     const uint16_t* tile_counts, const uint32_t* scalars, SortGeom g,
-                                                     uint32_t nbins) {
+__global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, const uint32_t* tile_offs, const uint32_t* bin_base,
+                                                        const uint16_t* tile_counts, const uint32_t* scalars, SortGeom g,
+                                                        uint32_t nbins) {
   constexpr int HALVES = GLV ? 2 : 1;
   constexpr int SC = COARSE_ITEMS / HALVES;           // scalars per thread
   extern __shared__ uint32_t s_dyn[];
-  uint32_t* s_off = s_dyn;                  // [nbins] counts, then offsets inside the tile's staging order
-  uint32_t* s_cur = s_dyn + nbins;          // [nbins] running rank counters
-  uint32_t* s_gbase = s_dyn + 2 * nbins;    // [nbins] global address of this tile's run in each bin
+  uint32_t* s_cur = s_dyn;                  // [nbins] cursor: next staging position of the bin (starts at its staging offset)
+  uint32_t* s_delta = s_dyn + nbins;        // [nbins] (global index of the tile's run in the bin) - (staging offset)
   __shared__ uint32_t s_stage[2][COARSE_TILE];   // staged words, in bin order
   __shared__ uint32_t s_dst[2][COARSE_TILE];     // ... and where each one goes in packed_out
   __shared__ uint32_t s_wave[COARSE_T / 64];
-  __shared__ uint32_t s_total;
+  __shared__ uint32_t s_wstart[kMaxWindowsSort + 1];   // staging offset of every window's first bin; [K] = tile total
   const uint32_t L = 1u << (g.c - 1);
   const uint32_t fmask = (1u << g.fb) - 1u;
+#ifdef MSMZ_TRACE
+  uint64_t* trace = reinterpret_cast<uint64_t*>(const_cast<uint32_t*>(tile_offs) + (size_t)gridDim.x * nbins);
+#endif
+  MSMZ_STAMP(trace, 0);
+  MSMZ_STAMP_HW(trace);
 
   DigitStream<Fr, GLV> ds[SC];
   uint32_t idx[SC];
@@ -260,42 +299,39 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
     idx[s] = (blockIdx.x * SC + s) * COARSE_T + threadIdx.x;
     if (idx[s] < g.n) ds[s].load(scalars, idx[s]); else ds[s].clear();
   }
-  // reserve the runs (all bins at once), scan the counts
   {
     const uint16_t* row = tile_counts + (size_t)blockIdx.x * nbins;
+    const uint32_t* roff = tile_offs + (size_t)blockIdx.x * nbins;
     const uint32_t per = (nbins + COARSE_T - 1) / COARSE_T;   // consecutive bins per thread
     const uint32_t b0 = threadIdx.x * per;
+    const int lncb = g.c - 1 - g.fb;
     uint32_t sum = 0;
     for (uint32_t q = 0; q < per; q++) {
       const uint32_t b = b0 + q;
-      if (b < nbins) {
-        const uint32_t cnt = row[b];
-        s_cur[b] = 0;
-        s_gbase[b] = cnt ? bin_base[b] + atomicAdd(&bin_cursor[b], cnt) : 0u;
-        sum += cnt;
-      }
+      if (b < nbins) sum += row[b];
     }
     uint32_t total;
     uint32_t ex = block_exclusive_scan<COARSE_T>(sum, &total, s_wave);
     for (uint32_t q = 0; q < per; q++) {
       const uint32_t b = b0 + q;
       if (b < nbins) {
-        s_off[b] = ex;          // relative to the tile's first entry: the window start is subtracted below
+        s_cur[b] = ex;
+        s_delta[b] = bin_base[b] + roff[b] - ex;
+        if ((b & (g.ncb - 1u)) == 0 && (b >> lncb) < (uint32_t)g.K) s_wstart[b >> lncb] = ex;   // ncb is a power of two
         ex += row[b];
       }
     }
-    if (threadIdx.x == 0) s_total = total;
+    if (threadIdx.x == 0) s_wstart[g.K] = total;
   }
   __syncthreads();
-#pragma unroll 1
-  for (int k = 0; k < g.K; k++) {
+  MSMZ_STAMP(trace, 1);
+  auto window = [&](const int k, auto is_top) {
+    constexpr bool TOP = decltype(is_top)::value;
     const int buf = k & 1;
-    const bool top = k == g.K - 1;
-    const uint32_t smask = top ? (1u << g.spread) - 1u : 0u;
-    const uint32_t ncbk = top ? g.ncb << g.spread : g.ncb;   // bins of this window (its sub-windows follow each other)
-    const uint32_t* off_k = s_off + (uint32_t)k * g.ncb;
+    const uint32_t wbase = s_wstart[k];
+    const uint32_t wcnt = s_wstart[TOP ? g.K : k + 1] - wbase;
     uint32_t* cur_k = s_cur + (uint32_t)k * g.ncb;
-    const uint32_t wbase = off_k[0];
+    const uint32_t* delta_k = s_delta + (uint32_t)k * g.ncb;
 #pragma unroll
     for (int s = 0; s < SC; s++) {
 #pragma unroll
@@ -304,12 +340,17 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
         const uint32_t l = ds[s].next(h, k, g.c, L, ng);
         if (l != 0) {
           const uint32_t entry = (uint32_t)h * g.n + idx[s];
-          const uint32_t bi = bucket_index(g, k, l, entry);
-          const uint32_t bin = (entry & smask) * g.ncb + (bi >> g.fb);
-          const uint32_t rank = atomicAdd(&cur_k[bin], 1u);
-          const uint32_t pos = off_k[bin] - wbase + rank;
+          uint32_t bi = l - 1u, bin;
+          if constexpr (TOP) {
+            bi = bucket_index(g, k, l, entry);
+            bin = (entry & ((1u << g.spread) - 1u)) * g.ncb + (bi >> g.fb);
+          } else {
+            bin = bi >> g.fb;
+          }
+          const uint32_t pa = atomicAdd(&cur_k[bin], 1u);   // staging position, tile-relative
+          const uint32_t pos = pa - wbase;
           s_stage[buf][pos] = ((bi & fmask) << (g.idx_bits + 1)) | (ng << g.idx_bits) | entry;
-          s_dst[buf][pos] = s_gbase[(uint32_t)k * g.ncb + bin] + rank;
+          s_dst[buf][pos] = delta_k[bin] + pa;
         }
       }
     }
@@ -317,9 +358,20 @@ __global__ void __launch_bounds__(COARSE_T) k_coarse(uint32_t* packed_out, uint3
     // all threads copy the staged window out: consecutive staged words of a bin go to consecutive addresses, so every
     // run is a contiguous, coalesced store.  The next window stages into the other buffer; the barrier of the window
     // after that orders this buffer's reuse behind these reads.
-    const uint32_t wend = (uint32_t)k * g.ncb + ncbk < nbins ? off_k[ncbk] : s_total;
-    for (uint32_t p = threadIdx.x; p < wend - wbase; p += COARSE_T) packed_out[s_dst[buf][p]] = s_stage[buf][p];
+#pragma unroll
+    for (int q = 0; q < COARSE_ITEMS; q++) {
+      const uint32_t p = (uint32_t)q * COARSE_T + threadIdx.x;
+      if (p < wcnt) packed_out[s_dst[buf][p]] = s_stage[buf][p];
+    }
+  };
+#pragma unroll 1
+  for (int k = 0; k < g.K - 1; k++) {
+    if (k == 1) MSMZ_STAMP(trace, 2);
+    window(k, std::false_type{});
   }
+  MSMZ_STAMP(trace, 3);
+  window(g.K - 1, std::true_type{});
+  MSMZ_STAMP(trace, 4);
 }
 
 // ------------------------------------------------------------------------------------------------ fine sort
@@ -334,13 +386,20 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
   uint32_t* s_stage = s_dyn + (1 << FINE_MAX_BITS);          // [FINE_STAGE]
   __shared__ uint32_t s_wave[FINE_T / 64];
   __shared__ uint32_t s_wmax[FINE_T / 64];
-  const uint32_t bin = blockIdx.x;
+  // last bins first: the top window's bins are the only ones that are structurally above average (its digit range is
+  // not a power of two, so its buckets are up to 2x denser), and the workgroups that start first should be the long ones
+  const uint32_t bin = n_bins - 1u - blockIdx.x;
   const uint32_t nfine = 1u << fb;
   const uint32_t per = (nfine + FINE_T - 1) / FINE_T;        // consecutive buckets per thread (<= 2)
   const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
   const uint32_t cnt_bin = end - begin;
   const bool staged = cnt_bin <= (uint32_t)FINE_STAGE;   // the bin fits the threads' registers (and the LDS staging)
   const uint32_t imask = (1u << idx_bits) - 1u;
+#ifdef MSMZ_TRACE
+  uint64_t* trace = reinterpret_cast<uint64_t*>(const_cast<uint32_t*>(bin_base) + ((n_bins + 2) & ~1u));
+#endif
+  MSMZ_STAMP(trace, 0);
+  MSMZ_STAMP_HW(trace);
   for (uint32_t f = threadIdx.x; f < nfine; f += FINE_T) s_cnt[f] = 0;
   // the bin's entries: all loads of a thread are issued back to back (the bin is read ONCE)
   uint32_t v[FINE_PER];
@@ -352,6 +411,7 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
     }
   }
   __syncthreads();
+  MSMZ_STAMP(trace, 1);
   // histogram; on the staged path the atomic's return value IS the entry's rank inside its bucket (kept in a register),
   // so no second round of atomics is needed: position = bucket offset + rank
   uint32_t rank[FINE_PER];
@@ -362,9 +422,20 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
       if ((uint32_t)j * FINE_T + threadIdx.x < cnt_bin) rank[j] = atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
     }
   } else {
-    for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) atomicAdd(&s_cnt[packed[p] >> (idx_bits + 1)], 1u);
+    // a bin beyond the staging: same register array, FINE_STAGE entries at a time (all of a chunk's loads in flight)
+    for (uint32_t c0 = 0; c0 < cnt_bin; c0 += FINE_STAGE) {
+#pragma unroll
+      for (int j = 0; j < FINE_PER; j++) {
+        const uint32_t p = c0 + (uint32_t)j * FINE_T + threadIdx.x;
+        v[j] = p < cnt_bin ? packed[begin + p] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < FINE_PER; j++)
+        if (c0 + (uint32_t)j * FINE_T + threadIdx.x < cnt_bin) atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
+    }
   }
   __syncthreads();
+  MSMZ_STAMP(trace, 2);
   uint32_t mine = 0, mx = 0, cnts[2] = {0, 0};
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t f = threadIdx.x * per + j;
@@ -412,6 +483,7 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
   }
   if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
   __syncthreads();
+  MSMZ_STAMP(trace, 3);
   auto to_ref = [&](uint32_t pv) {
     uint32_t idx = pv & imask;
     if (idx >= n_half) idx += endo_delta;   // endomorphism half: record index in the point set
@@ -426,14 +498,28 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
       }
     }
     __syncthreads();
+    MSMZ_STAMP(trace, 4);
     for (uint32_t p = threadIdx.x; p < cnt_bin; p += FINE_T) refs[begin + p] = s_stage[p];
+    MSMZ_STAMP(trace, 5);
   } else {
-    // a bin too large for the LDS staging (heavily repeated scalars): second read, scattered stores
-    for (uint32_t p = begin + threadIdx.x; p < end; p += FINE_T) {
-      const uint32_t pv = packed[p];
-      const uint32_t pos = atomicAdd(&s_cnt[pv >> (idx_bits + 1)], 1u);
-      refs[begin + pos] = to_ref(pv);
+    // a bin too large for the LDS staging (a dense top window, heavily repeated scalars): second read in the same
+    // chunks, running cursors in LDS, scattered stores (the bin's range is L2-resident while it is written)
+    for (uint32_t c0 = 0; c0 < cnt_bin; c0 += FINE_STAGE) {
+#pragma unroll
+      for (int j = 0; j < FINE_PER; j++) {
+        const uint32_t p = c0 + (uint32_t)j * FINE_T + threadIdx.x;
+        v[j] = p < cnt_bin ? packed[begin + p] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < FINE_PER; j++) {
+        if (c0 + (uint32_t)j * FINE_T + threadIdx.x < cnt_bin) {
+          const uint32_t pos = atomicAdd(&s_cnt[v[j] >> (idx_bits + 1)], 1u);
+          refs[begin + pos] = to_ref(v[j]);
+        }
+      }
     }
+    MSMZ_STAMP(trace, 4);
+    MSMZ_STAMP(trace, 5);
   }
 }
 
