@@ -163,15 +163,18 @@ class Engine : public IEngine {
     // the device's per-workgroup LDS, so a kernel that cannot launch fails context creation with its name.
     int st;
     if ((st = raise_lds_limit((const void*)k_fine, "k_fine", kFineLds))) return st;
-    if ((st = raise_lds_limit((const void*)k_coarse<Fr, false>, "k_coarse", kCoarseLdsMax))) return st;
-    if ((st = raise_lds_limit((const void*)k_hist<Fr, false>, "k_hist", kHistLdsMax))) return st;
+    if ((st = raise_sort_limits<false, 0>()) || (st = raise_sort_limits<false, 16>()) || (st = raise_sort_limits<false, 17>())) return st;
     if constexpr (Fr::HAS_GLV) {
-      if ((st = raise_lds_limit((const void*)k_coarse<Fr, true>, "k_coarse<glv>", kCoarseLdsMax))) return st;
-      if ((st = raise_lds_limit((const void*)k_hist<Fr, true>, "k_hist<glv>", kHistLdsMax))) return st;
+      if ((st = raise_sort_limits<true, 0>()) || (st = raise_sort_limits<true, 16>())) return st;
     }
     return meta_.ensure(sizeof(MsmMeta));
   }
-
+  template <bool GLV, int C>
+  int raise_sort_limits() {
+    int st;
+    if ((st = raise_lds_limit((const void*)k_coarse<Fr, GLV, C>, GLV ? "k_coarse<glv>" : "k_coarse", kCoarseLdsMax))) return st;
+    return raise_lds_limit((const void*)k_hist<Fr, GLV, C>, GLV ? "k_hist<glv>" : "k_hist", kHistLdsMax);
+  }
   // dynamic LDS the sort kernels may be launched with (sort_phase never asks for more: SORT_MAX_BINS caps nbins)
   static constexpr size_t kFineLds = ((size_t)(1 << FINE_MAX_BITS) + FINE_STAGE) * 4;
   static constexpr size_t kCoarseLdsMax = (size_t)2 * SORT_MAX_BINS * 4;
@@ -806,33 +809,43 @@ class Engine : public IEngine {
       const uint32_t tiles = (n + per_tile - 1) / per_tile;
       if ((st = tilecnt_.ensure((size_t)tiles * nbins * 2))) return st;
       if ((st = tileoff_.ensure((size_t)tiles * nbins * 4 + kTraceBytes * tiles))) return st;   // the tiles' runs inside the bins
-      if (pl.glv) {
-        if constexpr (Fr::HAS_GLV)
-          hipLaunchKernelGGL((k_hist<Fr, true>), dim3(tiles), dim3(COARSE_T), (size_t)nbins * 4, stream_, d_counts,
+      // kernels specialized for the window size (unrolled window loop) where one is compiled: 16 / 17, the defaults of
+      // large inputs; any other window size takes the generic ones
+      const int cspec = (no_sort_special_ || (c != 16 && c != 17) || (pl.glv && c != 16)) ? 0 : c;
+      auto launch_sort = [&](auto glvc, auto cc, bool coarse) {
+        constexpr bool G = decltype(glvc)::value;
+        constexpr int C = decltype(cc)::value;
+        if (!coarse)
+          hipLaunchKernelGGL((k_hist<Fr, G, C>), dim3(tiles), dim3(COARSE_T), (size_t)nbins * 4, stream_, d_counts,
                              tilecnt_.as<uint16_t>(), tileoff_.as<uint32_t>(), d_meta, d_scalars, g, nbins);
-      } else {
-        hipLaunchKernelGGL((k_hist<Fr, false>), dim3(tiles), dim3(COARSE_T), (size_t)nbins * 4, stream_, d_counts,
-                           tilecnt_.as<uint16_t>(), tileoff_.as<uint32_t>(), d_meta, d_scalars, g, nbins);
-      }
+        else   // dynamic LDS <= kCoarseLdsMax (nbins <= SORT_MAX_BINS): the limit init() raised
+          hipLaunchKernelGGL((k_coarse<Fr, G, C>), dim3(tiles), dim3(COARSE_T), (size_t)2 * nbins * 4, stream_,
+                             packed_.as<uint32_t>(), tileoff_.as<uint32_t>(), bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(),
+                             d_scalars, g, nbins);
+      };
+      auto dispatch_sort = [&](bool coarse) {
+        using std::integral_constant;
+        if (pl.glv) {
+          if constexpr (Fr::HAS_GLV) {
+            if (cspec == 16) launch_sort(std::true_type{}, integral_constant<int, 16>{}, coarse);
+            else launch_sort(std::true_type{}, integral_constant<int, 0>{}, coarse);
+          }
+        } else if (cspec == 17) {
+          launch_sort(std::false_type{}, integral_constant<int, 17>{}, coarse);
+        } else if (cspec == 16) {
+          launch_sort(std::false_type{}, integral_constant<int, 16>{}, coarse);
+        } else {
+          launch_sort(std::false_type{}, integral_constant<int, 0>{}, coarse);
+        }
+      };
+      dispatch_sort(false);
       mark(pl);  // 1
       MSMZ_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream_, bins_.as<uint32_t>(), d_counts, nbins,
                          &d_meta->n_entries);
       mark(pl);  // 2
       MSMZ_HIP(hipGetLastError());
-      {
-        const uint32_t grid = tiles;
-        const size_t lds = (size_t)2 * nbins * 4;   // <= kCoarseLdsMax (nbins <= SORT_MAX_BINS): the limit init() raised
-        if (pl.glv) {
-          if constexpr (Fr::HAS_GLV) {
-            hipLaunchKernelGGL((k_coarse<Fr, true>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
-                               tileoff_.as<uint32_t>(), bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
-          }
-        } else {
-          hipLaunchKernelGGL((k_coarse<Fr, false>), dim3(grid), dim3(COARSE_T), lds, stream_, packed_.as<uint32_t>(),
-                             tileoff_.as<uint32_t>(), bins_.as<uint32_t>(), tilecnt_.as<uint16_t>(), d_scalars, g, nbins);
-        }
-      }
+      dispatch_sort(true);
       pl.ev_coarse = pl.ei;
       mark(pl);  // 3
       MSMZ_HIP(hipGetLastError());
@@ -1588,6 +1601,7 @@ class Engine : public IEngine {
   bool no_bucket_sums_ = env_int("MSMZ_NO_BUCKET_SUMS", 0) != 0;
   bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
+  bool no_sort_special_ = env_int("MSMZ_NO_SORT_SPECIAL", 0) != 0;   // generic sort kernels for every window size
   bool reduce2d_ = env_int("MSMZ_REDUCE2D", 1) != 0;          // two-dimensional bucket reduction (reduce2d_kernels.h); 0 = the grouped running sums
   int tail_skip_2d_ = env_int("MSMZ_TAIL_SKIP_2D", 1) > 2 ? 2 : env_int("MSMZ_TAIL_SKIP_2D", 1);
   uint32_t r2_nc_ = (uint32_t)env_int("MSMZ_R2_NC", 0);         // chunks per line (0 = automatic)

@@ -81,10 +81,16 @@
   PFX template __global__ void k_test_point<P, TE>(uint32_t*, const uint32_t*, const uint32_t*, const uint8_t*,   \
                                                    const uint8_t*, uint32_t, int);
 
+// sort kernels: window size 0 = any, 16 / 17 = the defaults of large inputs (window loop unrolled)
+#define MSMZ_INST_SORT(Fr, GLV, C, PFX)                                                                           \
+  PFX template __global__ void k_hist<Fr, GLV, C>(uint32_t*, uint16_t*, uint32_t*, MsmMeta*, const uint32_t*, SortGeom, uint32_t); \
+  PFX template __global__ void k_coarse<Fr, GLV, C>(uint32_t*, const uint32_t*, const uint32_t*, const uint16_t*, const uint32_t*, SortGeom, uint32_t);
+
 #define MSMZ_INST_SCALAR(Fr, PFX)                                                                                 \
   PFX template __global__ void k_digits<Fr, false>(uint32_t*, uint32_t*, MsmMeta*, const uint32_t*, uint32_t, int, int, int); \
-  PFX template __global__ void k_hist<Fr, false>(uint32_t*, uint16_t*, uint32_t*, MsmMeta*, const uint32_t*, SortGeom, uint32_t);       \
-  PFX template __global__ void k_coarse<Fr, false>(uint32_t*, const uint32_t*, const uint32_t*, const uint16_t*, const uint32_t*, SortGeom, uint32_t); \
+  MSMZ_INST_SORT(Fr, false, 0, PFX)                                                                               \
+  MSMZ_INST_SORT(Fr, false, 16, PFX)                                                                              \
+  MSMZ_INST_SORT(Fr, false, 17, PFX)                                                                              \
   PFX template __global__ void k_check_scalars<Fr>(uint32_t*, const uint32_t*, uint32_t);                         \
   PFX template __global__ void k_gen_scalars<Fr>(uint32_t*, uint32_t, uint64_t, GenMap);
 
@@ -92,8 +98,8 @@
   PFX template __global__ void k_points_to_mont<F>(uint32_t*, const uint32_t*, const uint8_t*, uint32_t, int, uint32_t*); \
   PFX template __global__ void k_points_from_mont<F>(uint32_t*, const uint32_t*, uint32_t);                       \
   PFX template __global__ void k_digits<Fr, true>(uint32_t*, uint32_t*, MsmMeta*, const uint32_t*, uint32_t, int, int, int); \
-  PFX template __global__ void k_hist<Fr, true>(uint32_t*, uint16_t*, uint32_t*, MsmMeta*, const uint32_t*, SortGeom, uint32_t);        \
-  PFX template __global__ void k_coarse<Fr, true>(uint32_t*, const uint32_t*, const uint32_t*, const uint16_t*, const uint32_t*, SortGeom, uint32_t); \
+  MSMZ_INST_SORT(Fr, true, 0, PFX)                                                                                \
+  MSMZ_INST_SORT(Fr, true, 16, PFX)                                                                               \
   PFX template __global__ void k_test_digits<Fr, true>(uint32_t*, const uint32_t*, uint32_t, int, int);           \
   MSMZ_INST_TEST(F, Fr, WeierPolicy<F>, false, PFX)                                                               \
   MSMZ_INST_SCALAR(Fr, PFX)

@@ -17,6 +17,8 @@
 //                 with all loads in flight at once, LDS histogram -> bucket offsets `off`, every reference placed at
 //                 its sorted position in LDS, streamed out coalesced; also the largest bucket size
 #pragma once
+#include <type_traits>
+#include <utility>
 
 namespace msmz {
 
@@ -66,6 +68,19 @@ __device__ __forceinline__ uint32_t bucket_index(const SortGeom& g, int k, uint3
   if (g.fold_shift != 0 && k == g.K - 1) return ((entry & ((1u << g.fold_rows) - 1u)) << g.fold_shift) + l - 1u;
   return l - 1u;
 }
+
+template <class F, int... Ks>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Ks...>) {
+  (f(std::integral_constant<int, Ks>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// windows a kernel specialized for window size CB unrolls: every position a (half-)scalar of WORDS words can have a digit at
+template <int WORDS, int CB>
+constexpr int windows_max() { return (WORDS * 32 + CB) / CB; }
 
 // The (half-)scalars of one input scalar as little-endian words.  Windows are sliced with a word index that is the
 // same for every lane (the window loop is wave-uniform), so a window costs two register moves out of a uniform
@@ -134,6 +149,34 @@ struct DigitStream {
     ng = (cy ^ (neg >> h)) & (l != 0 ? 1u : 0u);   // the half scalar's own sign flips every digit's sign
     return l;
   }
+  // The same with the window index and the window size known at compile time (the kernels specialized for the default
+  // window sizes unroll their window loop): the word index and the shift are immediates, a window costs one bit-field
+  // extract (or one funnel shift + mask when it straddles two words) instead of the uniform switch above.
+  template <int POS, int CB>
+  __device__ __forceinline__ uint32_t bits_c(int h) const {
+    constexpr int wi = POS >> 5, sh = POS & 31;
+    constexpr uint32_t mask = (1u << CB) - 1u;
+    if constexpr (wi >= WORDS) {
+      return 0u;
+    } else if constexpr (sh + CB <= 32 || wi + 1 >= WORDS) {
+      return (w[h][wi] >> sh) & mask;
+    } else {
+      return __builtin_amdgcn_alignbit(w[h][wi + 1 < WORDS ? wi + 1 : wi], w[h][wi], (uint32_t)sh) & mask;
+    }
+  }
+  template <int KW, int CB>
+  __device__ __forceinline__ uint32_t next_c(int h, uint32_t& ng) {
+    constexpr uint32_t L = 1u << (CB - 1);
+    uint32_t l = bits_c<KW * CB, CB>(h) + ((carry >> h) & 1u);
+    uint32_t cy = 0;
+    if (l > L) {
+      l = 2 * L - l;
+      cy = 1;
+    }
+    carry = (carry & ~(1u << h)) | (cy << h);
+    ng = (cy ^ (neg >> h)) & (l != 0 ? 1u : 0u);
+    return l;
+  }
   // does the scalar need more than K windows?  (a carry out of the last one, or bits beyond it)
   __device__ __forceinline__ bool overflows(int K, int c) const {
     uint32_t o = carry & ((1u << HALVES) - 1u);
@@ -159,7 +202,8 @@ __device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_
 // counts[bin] += entries; meta->error |= 2 when a scalar does not fit K windows (a GLV half above the assumed
 // bound: the host then repeats the MSM with one more bit), |= 4 when a scalar is not below the group order
 // (scalarsFromBytes' precondition, checked here instead of in a serial host loop).
-template <class Fr, bool GLV>
+// C > 0: specialized for window size C (window loop unrolled, DigitStream::next_c); C = 0: any window size.
+template <class Fr, bool GLV, int C>
 __global__ void __launch_bounds__(COARSE_T, 8) k_hist(uint32_t* counts, uint16_t* tile_counts, uint32_t* tile_offs, MsmMeta* meta,
                                                  const uint32_t* scalars, SortGeom g, uint32_t nbins) {
   extern __shared__ uint32_t s_hist[];
@@ -181,17 +225,25 @@ __global__ void __launch_bounds__(COARSE_T, 8) k_hist(uint32_t* counts, uint16_t
       ds[it].clear();
     }
   }
-#pragma unroll 1
-  for (int k = 0; k < g.K; k++) {
+  auto window = [&](auto kk) {
+    const int k = kk;
 #pragma unroll
     for (int it = 0; it < PER; it++) {
 #pragma unroll
       for (int h = 0; h < HALVES; h++) {
-        uint32_t ng;
-        const uint32_t l = ds[it].next(h, k, g.c, L, ng);
+        uint32_t ng, l;
+        if constexpr (C > 0) l = ds[it].template next_c<decltype(kk)::value, C>(h, ng); else l = ds[it].next(h, k, g.c, L, ng);
         if (l != 0) atomicAdd(&s_hist[coarse_bin(g, k, l, (uint32_t)h * g.n + idx[it])], 1u);
       }
     }
+  };
+  if constexpr (C > 0) {
+    static_for<windows_max<DigitStream<Fr, GLV>::WORDS, C>()>([&](auto kc) {
+      if (decltype(kc)::value < g.K) window(kc);
+    });
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < g.K; k++) window(k);
   }
 #pragma unroll
   for (int it = 0; it < PER; it++)
@@ -271,7 +323,7 @@ static __global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* base, const 
 //            offset), stage them in LDS in bin order, write every bin's entries as one contiguous run.  Double-buffered
 //            staging: 1 barrier per window.
 // Algorithmic HBM bytes: 32 B read per scalar + 4 B written per entry.  Dynamic LDS: 2 * nbins words.
-template <class Fr, bool GLV>
+template <class Fr, bool GLV, int C>
 __global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, const uint32_t* tile_offs, const uint32_t* bin_base,
                                                         const uint16_t* tile_counts, const uint32_t* scalars, SortGeom g,
                                                         uint32_t nbins) {
@@ -280,8 +332,8 @@ __global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, co
   extern __shared__ uint32_t s_dyn[];
   uint32_t* s_cur = s_dyn;                  // [nbins] cursor: next staging position of the bin (starts at its staging offset)
   uint32_t* s_delta = s_dyn + nbins;        // [nbins] (global index of the tile's run in the bin) - (staging offset)
+  static_assert(COARSE_TILE == 2048 && COARSE_MAX_BINS <= 512 && FINE_MAX_BITS <= 11, "staged word: 11 + 1 + 11 + 9 bits");
   __shared__ uint32_t s_stage[2][COARSE_TILE];   // staged words, in bin order
-  __shared__ uint32_t s_dst[2][COARSE_TILE];     // ... and where each one goes in packed_out
   __shared__ uint32_t s_wave[COARSE_T / 64];
   __shared__ uint32_t s_wstart[kMaxWindowsSort + 1];   // staging offset of every window's first bin; [K] = tile total
   const uint32_t L = 1u << (g.c - 1);
@@ -325,52 +377,85 @@ __global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, co
   }
   __syncthreads();
   MSMZ_STAMP(trace, 1);
-  auto window = [&](const int k, auto is_top) {
+  // Stage window k into buffer `buf` in bin order.  A staged word is (fine | negate) << 20 | local index << 9 | bin: the
+  // bin rides along (<= 512 bins per window, 2048 half-scalars per tile: 11 + 1 + 11 + 9 bits), so the copy-out finds the
+  // run's address from the word itself and no second LDS array of destinations is written and read per entry.
+  auto stage = [&](auto kk, const int buf, auto is_top) {
     constexpr bool TOP = decltype(is_top)::value;
-    const int buf = k & 1;
+    const int k = kk;
     const uint32_t wbase = s_wstart[k];
-    const uint32_t wcnt = s_wstart[TOP ? g.K : k + 1] - wbase;
     uint32_t* cur_k = s_cur + (uint32_t)k * g.ncb;
-    const uint32_t* delta_k = s_delta + (uint32_t)k * g.ncb;
 #pragma unroll
     for (int s = 0; s < SC; s++) {
 #pragma unroll
       for (int h = 0; h < HALVES; h++) {
-        uint32_t ng;
-        const uint32_t l = ds[s].next(h, k, g.c, L, ng);
+        uint32_t ng, l;
+        if constexpr (C > 0) l = ds[s].template next_c<decltype(kk)::value, C>(h, ng); else l = ds[s].next(h, k, g.c, L, ng);
         if (l != 0) {
-          const uint32_t entry = (uint32_t)h * g.n + idx[s];
           uint32_t bi = l - 1u, bin;
           if constexpr (TOP) {
+            const uint32_t entry = (uint32_t)h * g.n + idx[s];
             bi = bucket_index(g, k, l, entry);
             bin = (entry & ((1u << g.spread) - 1u)) * g.ncb + (bi >> g.fb);
           } else {
             bin = bi >> g.fb;
           }
+          const uint32_t local = (uint32_t)(h * SC + s) * COARSE_T + threadIdx.x;   // < COARSE_TILE
           const uint32_t pa = atomicAdd(&cur_k[bin], 1u);   // staging position, tile-relative
-          const uint32_t pos = pa - wbase;
-          s_stage[buf][pos] = ((bi & fmask) << (g.idx_bits + 1)) | (ng << g.idx_bits) | entry;
-          s_dst[buf][pos] = delta_k[bin] + pa;
+          s_stage[buf][pa - wbase] = ((((bi & fmask) << 1) | ng) << 20) | (local << 9) | bin;
         }
       }
     }
-    __syncthreads();
-    // all threads copy the staged window out: consecutive staged words of a bin go to consecutive addresses, so every
-    // run is a contiguous, coalesced store.  The next window stages into the other buffer; the barrier of the window
-    // after that orders this buffer's reuse behind these reads.
+  };
+  // ... and, after a barrier, all threads copy it out: consecutive staged words of a bin go to consecutive addresses, so
+  // every run is a contiguous, coalesced store
+  auto copy_out = [&](const int k, const int buf) {
+    const uint32_t wbase = s_wstart[k];
+    const uint32_t wcnt = s_wstart[k == g.K - 1 ? g.K : k + 1] - wbase;
+    const uint32_t* delta_k = s_delta + (uint32_t)k * g.ncb;
 #pragma unroll
     for (int q = 0; q < COARSE_ITEMS; q++) {
       const uint32_t p = (uint32_t)q * COARSE_T + threadIdx.x;
-      if (p < wcnt) packed_out[s_dst[buf][p]] = s_stage[buf][p];
+      if (p < wcnt) {
+        const uint32_t w = s_stage[buf][p];
+        const uint32_t local = (w >> 9) & (COARSE_TILE - 1);
+        uint32_t entry;
+        if constexpr (GLV) entry = (local / COARSE_T) * g.n + blockIdx.x * COARSE_T + (local % COARSE_T);   // SC = 1
+        else entry = blockIdx.x * COARSE_TILE + local;
+        packed_out[delta_k[w & 511u] + wbase + p] = ((w >> 20) << g.idx_bits) | entry;
+      }
     }
   };
+  // one window per barrier, two buffers: the next window stages into the other buffer; the barrier of the window after
+  // that orders this buffer's reuse behind these reads.  (Two windows per barrier with four buffers measured slower.)
+  if constexpr (C > 0) {
+    static_for<windows_max<DigitStream<Fr, GLV>::WORDS, C>()>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (k == 1) MSMZ_STAMP(trace, 2);
+      if (k < g.K) {
+        if (k == g.K - 1) {
+          MSMZ_STAMP(trace, 3);
+          stage(kc, k & 1, std::true_type{});
+        } else {
+          stage(kc, k & 1, std::false_type{});
+        }
+        __syncthreads();
+        copy_out(k, k & 1);
+      }
+    });
+  } else {
 #pragma unroll 1
-  for (int k = 0; k < g.K - 1; k++) {
-    if (k == 1) MSMZ_STAMP(trace, 2);
-    window(k, std::false_type{});
+    for (int k = 0; k < g.K - 1; k++) {
+      if (k == 1) MSMZ_STAMP(trace, 2);
+      stage(k, k & 1, std::false_type{});
+      __syncthreads();
+      copy_out(k, k & 1);
+    }
+    MSMZ_STAMP(trace, 3);
+    stage(g.K - 1, (g.K - 1) & 1, std::true_type{});
+    __syncthreads();
+    copy_out(g.K - 1, (g.K - 1) & 1);
   }
-  MSMZ_STAMP(trace, 3);
-  window(g.K - 1, std::true_type{});
   MSMZ_STAMP(trace, 4);
 }
 
