@@ -618,6 +618,7 @@ class Engine : public IEngine {
     int c, K, b;
     int Keff, spread;           // bucket windows incl. the top window's 2^spread sub-windows
     int fold_shift = 0, fold_rows = 0;   // ... or the top window folded into its own bucket set (SortGeom)
+    uint32_t top_range = 1;              // values the top window's digit can take
     bool glv, timing;
     uint32_t max_bucket = 0, n_entries = 0;
     uint32_t endo_delta = 0;    // GLV over a prefix of a set: half-1 entry i reads point record pts_n + i = (n + i) + endo_delta
@@ -641,6 +642,7 @@ class Engine : public IEngine {
   struct Geometry {
     int c, K, t_top, spread, Keff;
     uint32_t L;
+    uint32_t top_range = 0;   // number of values the top window's digit can take (<= L + 1)
     int fold_shift = 0, fold_rows = 0;   // thin top window folded into its own bucket set (sort_kernels.h SortGeom)
   };
   Geometry geometry(int c, bool glv, uint32_t M, int b, bool allow_fold = false) const {
@@ -656,6 +658,7 @@ class Engine : public IEngine {
         top |= (uint64_t)((Fr::Q[(pos + j) >> 5] >> ((pos + j) & 31)) & 1u) << j;
       top += 1;   // carry from the window below
       g.t_top = ceil_log2_u64(top + 1);
+      g.top_range = (uint32_t)(top + 1 > g.L ? g.L : top + 1);
     } else if (Fr::GLV_TYP_BITS + 1 - pos < g.t_top) {
       g.t_top = Fr::GLV_TYP_BITS + 1 - pos;
       if (g.t_top < 1) g.t_top = 1;
@@ -684,6 +687,7 @@ class Engine : public IEngine {
       const int fbx = fine_bits(c, M);
       while (g.spread > 0 && ((g.L >> fbx) << g.spread) > (uint32_t)COARSE_MAX_BINS) g.spread--;
     }
+    if (g.top_range == 0) g.top_range = g.t_top >= c - 1 ? g.L : 1u << g.t_top;
     g.Keff = g.K - 1 + (1 << g.spread);
     return g;
   }
@@ -700,6 +704,18 @@ class Engine : public IEngine {
     const uint64_t L = 1ull << (c - 1);
     while (fb > 0 && (((uint64_t)M << fb) / L) * 10 > (uint64_t)FINE_STAGE * 9) fb--;
     return fb;
+  }
+
+  // Fine bits of the TOP window's bins (SortGeom::fbt): its entries fall on top_range << spread buckets only (the largest
+  // scalar bounds the top digit), so they are up to 2x denser than M / L; as many fine bits as keep such a bin inside
+  // k_fine's staging, and no fewer than keep the window's bins inside k_coarse's 9-bit bin field.
+  int fine_bits_top(const Plan& pl, int fb) const {
+    if (pl.fold_shift != 0 || no_fbt_) return fb;
+    const uint64_t slots = (uint64_t)pl.top_range << pl.spread;
+    int fbt = fb;
+    while (fbt > 0 && (((uint64_t)pl.M << fbt) / slots) * 10 > (uint64_t)FINE_STAGE * 9) fbt--;
+    while (fbt < fb && ((pl.L >> fbt) << pl.spread) > (uint32_t)COARSE_MAX_BINS) fbt++;
+    return fbt;
   }
 
   // Default window size.  Large inputs (M >= 2^18: profiles/r03_sweep.json) are throughput-bound: c = log2 M - 3 capped at 17, stepped
@@ -766,6 +782,7 @@ class Engine : public IEngine {
     pl.K = g.K;
     pl.L = g.L;
     pl.spread = g.spread;
+    pl.top_range = g.top_range;
     pl.fold_shift = g.fold_shift;
     pl.fold_rows = g.fold_rows;
     pl.Keff = g.Keff;
@@ -793,9 +810,12 @@ class Engine : public IEngine {
     const int idx_bits = ceil_log2_u64(M < 2 ? 2 : M);
     const int fb = fine_bits(c, M);
     const uint32_t ncb = L >> fb;
-    const uint32_t nbins = (uint32_t)pl.Keff * ncb;
-    const bool sort2 = !force_atomic_sort_ && fb >= 0 && M <= (1u << 24) && (ncb << pl.spread) <= (uint32_t)COARSE_MAX_BINS &&
-                       nbins <= (uint32_t)SORT_MAX_BINS;
+    const int fbt = fine_bits_top(pl, fb);
+    const uint32_t ncbt = L >> fbt;
+    const uint32_t top_bin = (uint32_t)(K - 1) * ncb;
+    const uint32_t nbins = top_bin + (ncbt << pl.spread);
+    const bool sort2 = !force_atomic_sort_ && fb >= 0 && M <= (1u << 24) && ncb <= (uint32_t)COARSE_MAX_BINS &&
+                       (ncbt << pl.spread) <= (uint32_t)COARSE_MAX_BINS && nbins <= (uint32_t)SORT_MAX_BINS;
     const uint32_t n_half = pl.glv ? n : 0xffffffffu;
     if (sort2) {
       if ((st = packed_.ensure((size_t)K * M * 4))) return st;
@@ -803,7 +823,7 @@ class Engine : public IEngine {
       if ((st = counts_.ensure((size_t)nbins * 4))) return st;
       uint32_t* d_counts = counts_.as<uint32_t>();
       MSMZ_HIP(hipMemsetAsync(d_counts, 0, (size_t)nbins * 4, stream_));
-      SortGeom g{n, M, c, K, fb, pl.spread, idx_bits, ncb, pl.fold_shift, pl.fold_rows};
+      SortGeom g{n, M, c, K, fb, pl.spread, idx_bits, ncb, fbt, ncbt, pl.fold_shift, pl.fold_rows};
       mark(pl);  // 0
       const uint32_t per_tile = pl.glv ? COARSE_TILE / 2 : COARSE_TILE;   // scalars per workgroup (k_hist and k_coarse)
       const uint32_t tiles = (n + per_tile - 1) / per_tile;
@@ -852,8 +872,8 @@ class Engine : public IEngine {
       {
         const size_t lds = kFineLds;
         hipLaunchKernelGGL(k_fine, dim3(nbins), dim3(FINE_T), lds, stream_, refs_.as<uint32_t>(), off_.as<uint32_t>(),
-                           &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, nbins, idx_bits, n_half,
-                           pl.endo_delta);
+                           &d_meta->max_bucket, packed_.as<uint32_t>(), bins_.as<uint32_t>(), fb, fbt, top_bin, nbins, idx_bits,
+                           n_half, pl.endo_delta);
       }
 #ifdef MSMZ_TRACE
       if (const char* path = getenv("MSMZ_TRACE_OUT")) {   // development aid: workgroup time stamps of k_coarse / k_fine
@@ -1601,6 +1621,7 @@ class Engine : public IEngine {
   bool no_bucket_sums_ = env_int("MSMZ_NO_BUCKET_SUMS", 0) != 0;
   bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
+  bool no_fbt_ = env_int("MSMZ_NO_FBT", 0) != 0;                     // top window's bins as wide as the others
   bool no_sort_special_ = env_int("MSMZ_NO_SORT_SPECIAL", 0) != 0;   // generic sort kernels for every window size
   bool reduce2d_ = env_int("MSMZ_REDUCE2D", 1) != 0;          // two-dimensional bucket reduction (reduce2d_kernels.h); 0 = the grouped running sums
   int tail_skip_2d_ = env_int("MSMZ_TAIL_SKIP_2D", 1) > 2 ? 2 : env_int("MSMZ_TAIL_SKIP_2D", 1);

@@ -56,6 +56,11 @@ struct SortGeom {
   uint32_t M;          // entries per window: n, or 2 n with GLV (entry n + i = endomorphism half of scalar i)
   int c, K, fb, spread, idx_bits;
   uint32_t ncb;        // coarse bins per bucket set = L >> fb
+  // The TOP window's bucket sets may use fewer fine bits (fbt <= fb, ncbt = L >> fbt bins each): its digit range is not a
+  // power of two, so its buckets are up to 2x denser than the other windows' and a bin of 2^fb of them would not fit
+  // k_fine's LDS staging.  Bins of windows 0..K-2 come first (ncb each), then the top window's sub-windows (ncbt each).
+  int fbt;
+  uint32_t ncbt;
   // A THIN top window (its digit has only a few significant bits) can be FOLDED into its own bucket set instead of
   // spread over sub-windows: bucket weight j = (entry mod 2^fold_rows) * 2^fold_shift + l, i.e. the L buckets of the set
   // hold 2^fold_rows copies ("rows") of the digit's small range, and the two-dimensional reduction's COLUMN sums are
@@ -193,9 +198,9 @@ struct DigitStream {
 
 // bucket set (window, or sub-window of the sparse top window) and coarse bin of a non-zero digit
 __device__ __forceinline__ uint32_t coarse_bin(const SortGeom& g, int k, uint32_t l, uint32_t entry) {
-  uint32_t kw = (uint32_t)k;
-  if (k == g.K - 1) kw += entry & ((1u << g.spread) - 1u);
-  return kw * g.ncb + (bucket_index(g, k, l, entry) >> g.fb);
+  const uint32_t bi = bucket_index(g, k, l, entry);
+  if (k == g.K - 1) return (uint32_t)k * g.ncb + (entry & ((1u << g.spread) - 1u)) * g.ncbt + (bi >> g.fbt);
+  return (uint32_t)k * g.ncb + (bi >> g.fb);
 }
 
 // ------------------------------------------------------------------------------------------------ histogram
@@ -337,7 +342,6 @@ __global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, co
   __shared__ uint32_t s_wave[COARSE_T / 64];
   __shared__ uint32_t s_wstart[kMaxWindowsSort + 1];   // staging offset of every window's first bin; [K] = tile total
   const uint32_t L = 1u << (g.c - 1);
-  const uint32_t fmask = (1u << g.fb) - 1u;
 #ifdef MSMZ_TRACE
   uint64_t* trace = reinterpret_cast<uint64_t*>(const_cast<uint32_t*>(tile_offs) + (size_t)gridDim.x * nbins);
 #endif
@@ -396,10 +400,11 @@ __global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, co
           if constexpr (TOP) {
             const uint32_t entry = (uint32_t)h * g.n + idx[s];
             bi = bucket_index(g, k, l, entry);
-            bin = (entry & ((1u << g.spread) - 1u)) * g.ncb + (bi >> g.fb);
+            bin = (entry & ((1u << g.spread) - 1u)) * g.ncbt + (bi >> g.fbt);
           } else {
             bin = bi >> g.fb;
           }
+          const uint32_t fmask = (1u << (TOP ? g.fbt : g.fb)) - 1u;
           const uint32_t local = (uint32_t)(h * SC + s) * COARSE_T + threadIdx.x;   // < COARSE_TILE
           const uint32_t pa = atomicAdd(&cur_k[bin], 1u);   // staging position, tile-relative
           s_stage[buf][pa - wbase] = ((((bi & fmask) << 1) | ng) << 20) | (local << 9) | bin;
@@ -463,9 +468,11 @@ __global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, co
 // `n_half` / `endo_delta`: with GLV the entry index i >= n_half is the endomorphism half of point i - n_half; its
 // record sits at index i + endo_delta of the point set (the images follow the whole set, which may be larger than
 // the prefix this MSM covers: msm-batched-affine.ts:74-97 takes any N <= allocated).
+// Bins below `top_bin` hold 2^fb buckets each, the top window's bins (from `top_bin` on) 2^fbt.
 static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t* off, uint32_t* max_bucket,
-                                                 const uint32_t* packed, const uint32_t* bin_base, int fb,
-                                                 uint32_t n_bins, int idx_bits, uint32_t n_half, uint32_t endo_delta) {
+                                                 const uint32_t* packed, const uint32_t* bin_base, int fb, int fbt,
+                                                 uint32_t top_bin, uint32_t n_bins, int idx_bits, uint32_t n_half,
+                                                 uint32_t endo_delta) {
   extern __shared__ uint32_t s_dyn[];
   uint32_t* s_cnt = s_dyn;                                  // [1 << FINE_MAX_BITS] counts, then running cursors
   uint32_t* s_stage = s_dyn + (1 << FINE_MAX_BITS);          // [FINE_STAGE]
@@ -474,10 +481,18 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
   // last bins first: the top window's bins are the only ones that are structurally above average (its digit range is
   // not a power of two, so its buckets are up to 2x denser), and the workgroups that start first should be the long ones
   const uint32_t bin = n_bins - 1u - blockIdx.x;
-  const uint32_t nfine = 1u << fb;
+  const bool top = bin >= top_bin;
+  const uint32_t nfine = 1u << (top ? fbt : fb);
+  // first bucket of the bin in `off`
+  const size_t bucket0 = top ? ((size_t)top_bin << fb) + ((size_t)(bin - top_bin) << fbt) : (size_t)bin << fb;
   const uint32_t per = (nfine + FINE_T - 1) / FINE_T;        // consecutive buckets per thread (<= 2)
   const uint32_t begin = bin_base[bin], end = bin_base[bin + 1];
   const uint32_t cnt_bin = end - begin;
+  if (cnt_bin == 0) {   // (the top window's bins beyond its digit range): every bucket is empty and starts at `begin`
+    for (uint32_t f = threadIdx.x; f < nfine; f += FINE_T) off[bucket0 + f] = begin;
+    if (bin + 1 == n_bins && threadIdx.x == 0) off[bucket0 + nfine] = end;
+    return;
+  }
   const bool staged = cnt_bin <= (uint32_t)FINE_STAGE;   // the bin fits the threads' registers (and the LDS staging)
   const uint32_t imask = (1u << idx_bits) - 1u;
 #ifdef MSMZ_TRACE
@@ -557,7 +572,7 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
     const uint32_t f = threadIdx.x * per + j;
     if (f < nfine) {
       s_cnt[f] = ex;                                         // the bucket's offset (running cursor on the unstaged path)
-      off[(size_t)bin * nfine + f] = begin + ex;
+      off[bucket0 + f] = begin + ex;
       ex += cnts[j & 1];
     }
   }
@@ -566,7 +581,7 @@ static __global__ void __launch_bounds__(FINE_T) k_fine(uint32_t* refs, uint32_t
     for (int w2 = 0; w2 < FINE_T / 64; w2++) bmx = s_wmax[w2] > bmx ? s_wmax[w2] : bmx;
     if (bmx > 1) atomicMax(max_bucket, bmx);
   }
-  if (bin + 1 == n_bins && threadIdx.x == 0) off[(size_t)n_bins * nfine] = end;
+  if (bin + 1 == n_bins && threadIdx.x == 0) off[bucket0 + nfine] = end;   // = off[number of buckets]
   __syncthreads();
   MSMZ_STAMP(trace, 3);
   auto to_ref = [&](uint32_t pv) {
