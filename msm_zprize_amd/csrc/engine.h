@@ -185,6 +185,27 @@ class Engine : public IEngine {
   static constexpr size_t kTraceBytes = 0;
 #endif
 
+#ifdef MSMZ_TRACE
+  // appends one section {name[32], n, n x 16 stamps} to the file MSMZ_TRACE_OUT names (`first` truncates it)
+  int trace_dump(const char* name, const void* d_stamps, uint32_t n_wgs, bool first) {
+    const char* path = getenv("MSMZ_TRACE_OUT");
+    if (!path) return MSMZ_OK;
+    MSMZ_HIP(hipStreamSynchronize(stream_));
+    std::vector<uint64_t> t((size_t)n_wgs * 16);
+    MSMZ_HIP(hipMemcpy(t.data(), d_stamps, t.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(path, first ? "wb" : "ab")) {
+      char nm[32] = {};
+      strncpy(nm, name, 31);
+      const uint64_t n = n_wgs;
+      fwrite(nm, 1, 32, f);
+      fwrite(&n, 8, 1, f);
+      fwrite(t.data(), 8, t.size(), f);
+      fclose(f);
+    }
+    return MSMZ_OK;
+  }
+#endif
+
   int raise_lds_limit(const void* fn, const char* name, size_t dyn_max) {
     hipFuncAttributes fa;
     memset(&fa, 0, sizeof(fa));
@@ -876,20 +897,9 @@ class Engine : public IEngine {
                            n_half, pl.endo_delta);
       }
 #ifdef MSMZ_TRACE
-      if (const char* path = getenv("MSMZ_TRACE_OUT")) {   // development aid: workgroup time stamps of k_coarse / k_fine
-        MSMZ_HIP(hipStreamSynchronize(stream_));
-        const uint32_t trace_tiles = tiles;
-        std::vector<uint64_t> tc((size_t)trace_tiles * 16), tf((size_t)nbins * 16);
-        MSMZ_HIP(hipMemcpy(tc.data(), tileoff_.as<uint32_t>() + (size_t)tiles * nbins, tc.size() * 8, hipMemcpyDeviceToHost));
-        MSMZ_HIP(hipMemcpy(tf.data(), bins_.as<uint32_t>() + ((nbins + 2) & ~1u), tf.size() * 8, hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(path, "wb")) {
-          const uint64_t hdr[2] = {trace_tiles, nbins};
-          fwrite(hdr, 8, 2, f);
-          fwrite(tc.data(), 8, tc.size(), f);
-          fwrite(tf.data(), 8, tf.size(), f);
-          fclose(f);
-        }
-      }
+      // development aid: workgroup time stamps of k_coarse / k_fine (tools/wg_timeline.py)
+      if ((st = trace_dump("k_coarse", tileoff_.as<uint32_t>() + (size_t)tiles * nbins, tiles, true))) return st;
+      if ((st = trace_dump("k_fine", bins_.as<uint32_t>() + ((nbins + 2) & ~1u), nbins, false))) return st;
 #endif
     } else {
       // fallback (window sizes whose coarse bins do not fit the LDS staging): digits materialized, one global
@@ -1206,7 +1216,7 @@ class Engine : public IEngine {
     const uint32_t n_chunks = (nb + chunk - 1) / chunk;
     // chunk totals per round, then the per-workgroup scratch of the rounds beyond PLAN_RL
     const size_t pair_words = (size_t)n_chunks * (PLAN_RMAX - PLAN_RL) * PLAN_T;
-    if ((st = rscan_.ensure(((size_t)PLAN_RMAX * n_chunks + pair_words) * 4))) return st;
+    if ((st = rscan_.ensure(((size_t)PLAN_RMAX * n_chunks + pair_words) * 4 + kTraceBytes * n_chunks))) return st;
     if ((st = desc_.ensure((size_t)pl.K * pl.M * 8))) return st;
     if ((st = bfin_.ensure((size_t)nb * 16))) return st;
     // the batched-affine first reduction level (opt.reserved[0] = 1) wants ONE sum per bucket: no rounds skipped
@@ -1219,6 +1229,9 @@ class Engine : public IEngine {
                        d_meta, rscan_.as<uint32_t>(), off_.as<uint32_t>(), refs_.as<uint32_t>(), nb, n_chunks,
                        tail_skip, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks, chunk);
     MSMZ_HIP(hipGetLastError());
+#ifdef MSMZ_TRACE
+    if ((st = trace_dump("k_plan_emit", rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks + pair_words, n_chunks, false))) return st;
+#endif
     if ((st = fetch_meta(pl))) return st;      // the ONE host round trip before the final fetch
     if (h_meta_->error & 4u) return MSMZ_ERR_RANGE;
     if (h_meta_->error & 2u) return MSMZ_ERR_RETRY_BITS;

@@ -26,9 +26,12 @@ constexpr int PLAN_T = 512;
 constexpr int PLAN_PER = 2;                       // consecutive buckets per thread (counting / scan phases)
 constexpr int PLAN_CHUNK = PLAN_T * PLAN_PER;     // buckets per workgroup
 constexpr int PLAN_RMAX = 26;                     // rounds supported (bucket sizes < 2^26)
-constexpr int PLAN_RL = 8;                        // rounds whose per-bucket pair numbers sit in LDS (one thread per PAIR);
-                                                  // later rounds (buckets > 256 entries) are emitted bucket by bucket
-constexpr int PLAN_TILE = 8192;                   // pairs whose owner buckets are expanded into LDS at a time
+constexpr int PLAN_RL = 6;                        // rounds whose per-bucket pair numbers sit in LDS (one thread per PAIR);
+                                                  // later rounds (buckets > 64 entries) are emitted bucket by bucket
+constexpr int PLAN_TILE = 4096;                   // pairs whose owner buckets are expanded into LDS at a time
+// (LDS: 6 x 4.1 KB of prefixes + 4.1 KB of offsets + 8 KB of owners = 37 KB: FOUR workgroups per CU, so that the 1024
+// chunks of a 2^20-point MSM are resident together; at 53 KB three were, and the fourth quarter ran as a second pass:
+// 95 us instead of ~50, profiles/r03_sort_wg_timeline.txt)
 constexpr uint32_t LOC_ORIG = 0x40000000u;        // location word: bit 30 = original point (bit 31 = negate), else slot record
 constexpr uint32_t LOC_NONE = 0xffffffffu;
 
@@ -71,7 +74,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_count(uint32_t* chunk_pa
   if ((int)threadIdx.x < PLAN_RMAX) chunk_pairs[(size_t)threadIdx.x * n_chunks + blockIdx.x] = (int)threadIdx.x < R ? s_tot[threadIdx.x] : 0u;
 }
 
-static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4* bfin, MsmMeta* meta,
+static __global__ void __launch_bounds__(PLAN_T, 8) k_plan_emit(uint2* desc, uint4* bfin, MsmMeta* meta,
                                                              const uint32_t* chunk_pairs, const uint32_t* off,
                                                              const uint32_t* refs, uint32_t nb, uint32_t n_chunks,
                                                              int tail_skip, uint32_t* pair_scratch, uint32_t chunk) {
@@ -85,6 +88,11 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
   uint32_t* s_pair = pair_scratch + (size_t)blockIdx.x * (PLAN_RMAX - PLAN_RL) * PLAN_T;
   __shared__ uint32_t s_wave[PLAN_T / 64];
   __shared__ uint16_t s_owner[PLAN_TILE];              // chunk bucket of every pair of the current tile
+#ifdef MSMZ_TRACE
+  uint64_t* trace = reinterpret_cast<uint64_t*>(pair_scratch + (size_t)gridDim.x * (PLAN_RMAX - PLAN_RL) * PLAN_T);
+#endif
+  MSMZ_STAMP(trace, 0);
+  MSMZ_STAMP_HW(trace);
   const int R = plan_rounds(meta->max_bucket, tail_skip);
   const int RL = R < PLAN_RL ? R : PLAN_RL;
   if (threadIdx.x < PLAN_RMAX) {
@@ -95,6 +103,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
   const uint32_t nbk = nb - g0 < chunk ? nb - g0 : chunk;   // buckets of this chunk
   for (uint32_t b = threadIdx.x; b <= nbk; b += PLAN_T) s_start[b] = off[g0 + b];
   __syncthreads();
+  MSMZ_STAMP(trace, 1);
   for (int r = 0; r < R; r++) {
     uint32_t tot = 0, pre = 0;
     for (uint32_t b = threadIdx.x; b < n_chunks; b += PLAN_T) {
@@ -113,6 +122,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     }
   }
   __syncthreads();
+  MSMZ_STAMP(trace, 2);
   if (threadIdx.x == 0) {
     uint32_t base = 0;
     for (int r = 0; r < PLAN_RMAX; r++) {
@@ -152,6 +162,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     }
   }
   __syncthreads();
+  MSMZ_STAMP(trace, 3);
   // location of the element at relative position `pos` of chunk bucket b before round r (see the header); prr = this
   // thread's running pair numbers for the rounds >= PLAN_RL (only meaningful on the bucket-by-bucket path)
   auto location = [&](uint32_t b, uint32_t st, uint32_t sz, uint32_t pos, int r) -> uint32_t {
@@ -182,15 +193,27 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
         for (uint32_t t = lo; t < hi; t++) s_owner[t - tile0] = (uint16_t)b;
       }
       __syncthreads();
+      if (r == 0) {
+        // round 0 (half of all pairs): both operands are original points, entries 2j and 2j + 1 of the bucket
 #pragma unroll 4
-      for (uint32_t t = tile0 + threadIdx.x; t < tile1; t += PLAN_T) {   // unrolled: four pairs' reference loads in flight
-        const uint32_t b = s_owner[t - tile0];
-        const uint32_t st = s_start[b], sz = s_start[b + 1] - st;
-        const uint32_t a = (t - s_pref[r][b]) << (r + 1);
-        d[t] = make_uint2(location(b, st, sz, a, r), location(b, st, sz, a + (1u << r), r));
+        for (uint32_t t = tile0 + threadIdx.x; t < tile1; t += PLAN_T) {   // unrolled: four pairs' reference loads in flight
+          const uint32_t b = s_owner[t - tile0];
+          const uint32_t e = s_start[b] + ((t - s_pref[0][b]) << 1);
+          const uint32_t r0 = refs[e], r1 = refs[e + 1];
+          d[t] = make_uint2((r0 & (REF_IDX | REF_NEG)) | LOC_ORIG, (r1 & (REF_IDX | REF_NEG)) | LOC_ORIG);
+        }
+      } else {
+#pragma unroll 4
+        for (uint32_t t = tile0 + threadIdx.x; t < tile1; t += PLAN_T) {
+          const uint32_t b = s_owner[t - tile0];
+          const uint32_t st = s_start[b], sz = s_start[b + 1] - st;
+          const uint32_t a = (t - s_pref[r][b]) << (r + 1);
+          d[t] = make_uint2(location(b, st, sz, a, r), location(b, st, sz, a + (1u << r), r));
+        }
       }
       __syncthreads();
     }
+    if (r < 6) MSMZ_STAMP(trace, 4 + r);
   }
   // rounds >= PLAN_RL (very long buckets) and the per-bucket records: bucket by bucket
 #pragma unroll 1
@@ -216,6 +239,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_emit(uint2* desc, uint4*
     bfin[g0 + b] = fin;
     for (int r = PLAN_RL; r < R; r++) s_pair[(r - PLAN_RL) * PLAN_T + threadIdx.x] += pairs_in_round(sz, r);   // -> next bucket
   }
+  MSMZ_STAMP(trace, 10);
 }
 
 }  // namespace msmz

@@ -1,5 +1,5 @@
 """Development aid: reads the workgroup time stamps a -DMSMZ_TRACE build writes (MSMZ_TRACE_OUT=file) and prints, per
-sort kernel, when workgroups start and end (100 MHz wall clock -> microseconds) and how long each phase takes.
+instrumented kernel, when workgroups start and end (100 MHz wall clock -> microseconds) and how long each phase takes.
 
   tools/build_variant.sh trace -DMSMZ_DEV -DMSMZ_TRACE
   MSMZ_LIB=variants/libmsmz_trace.so MSMZ_TRACE_OUT=gpurun_out/trace.bin python tools/stage20.py 20 0 0 3
@@ -8,42 +8,48 @@ sort kernel, when workgroups start and end (100 MHz wall clock -> microseconds) 
 import sys
 import numpy as np
 
+LABELS = {
+    "k_coarse": {1: "loads + scan", 2: "window 0", 3: "windows 1..K-2", 4: "last window + copy"},
+    "k_fine": {1: "zero + loads in flight", 2: "atomics (hist + rank)", 3: "scan + offsets", 4: "place", 5: "copy out"},
+    "k_plan_emit": {1: "bucket offsets", 2: "chunk totals", 3: "per-round scans", 4: "round 0", 5: "round 1", 6: "round 2",
+                    7: "round 3", 8: "round 4", 9: "round 5", 10: "later rounds + bucket records"},
+}
 
-def report(name, t, nslots, labels):
+
+def report(name, t):
     t = t.astype(np.int64)
     hw = t[:, 15]
+    used = [j for j in range(15) if (t[:, j] != 0).mean() > 0.5]
+    ok = np.all(t[:, used] != 0, axis=1)
+    print(f"{name}: {len(t)} workgroups ({int((~ok).sum())} with a stamp missing: other code path)")
+    t = t[ok]
+    hw = hw[ok]
     t0 = t[:, 0].min()
-    us = (t[:, :nslots] - t0) / 100.0
-    start, end = us[:, 0], us[:, nslots - 1]
-    print(f"{name}: {len(t)} workgroups, first start -> last end {end.max():.1f} us")
-    print(f"  start  min/median/p90/max  {start.min():.1f} {np.median(start):.1f} {np.percentile(start, 90):.1f} {start.max():.1f}")
-    print(f"  end    min/median/p90/max  {end.min():.1f} {np.median(end):.1f} {np.percentile(end, 90):.1f} {end.max():.1f}")
-    dur = end - start
-    print(f"  life   min/median/p90/max  {dur.min():.1f} {np.median(dur):.1f} {np.percentile(dur, 90):.1f} {dur.max():.1f}")
-    for j in range(1, nslots):
-        d = us[:, j] - us[:, j - 1]
-        print(f"    {labels[j - 1]:34s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f}")
-    late = start > np.median(dur) * 0.5
-    print(f"  workgroups starting after {np.median(dur) * 0.5:.1f} us (second pass): {int(late.sum())}")
-    cu = (hw & 0xFFFF) >> 8 & 0xF
-    se = (hw >> 13) & 0x7
-    xcc = (hw >> 32) & 0xF
-    key = xcc * 1000 + se * 16 + cu
+    us = (t - t0) / 100.0
+    start, end = us[:, used[0]], us[:, used[-1]]
+    print(f"  first start -> last end {end.max():.1f} us")
+    for nm, v in (("start", start), ("end", end), ("life", end - start)):
+        print(f"  {nm:6s} min/median/p90/max  {v.min():.1f} {np.median(v):.1f} {np.percentile(v, 90):.1f} {v.max():.1f}")
+    for a, b in zip(used[:-1], used[1:]):
+        d = us[:, b] - us[:, a]
+        lab = LABELS.get(name, {}).get(b, f"slot {a} -> {b}")
+        print(f"    {lab:34s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f}")
+    key = ((hw >> 32) & 0xF) * 1000 + ((hw >> 13) & 0x7) * 16 + ((hw >> 8) & 0xF)
     uniq, cnt = np.unique(key, return_counts=True)
     print(f"  distinct (xcc, se, cu) ids: {len(uniq)}, workgroups per id min/max {cnt.min()}/{cnt.max()}")
     hist, edges = np.histogram(start, bins=12)
-    print("  start histogram:", " ".join(f"{e:.0f}:{h}" for h, e in zip(hist, edges)))
+    print("  start histogram (us:count):", " ".join(f"{e:.0f}:{h}" for h, e in zip(hist, edges)))
 
 
 def main():
-    raw = np.fromfile(sys.argv[1], dtype=np.uint64)
-    tiles, nbins = int(raw[0]), int(raw[1])
-    tc = raw[2:2 + tiles * 16].reshape(tiles, 16)
-    tf = raw[2 + tiles * 16:2 + (tiles + nbins) * 16].reshape(nbins, 16)
-    report("k_coarse", tc, 5, ["loads + reserve + scan", "window 0", "windows 1..K-2", "last window + copy"])
-    report("k_fine", tf, 6, ["zero + loads in flight", "atomics (hist + rank)", "scan + offsets", "place", "copy out"])
-    t0c, t0f = tc[:, 0].min(), tf[:, 0].min()
-    print(f"k_fine first start - k_coarse first start: {(int(t0f) - int(t0c)) / 100.0:.1f} us")
+    raw = open(sys.argv[1], "rb").read()
+    pos = 0
+    while pos + 40 <= len(raw):
+        name = raw[pos:pos + 32].split(b"\0")[0].decode()
+        n = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=pos + 32)[0])
+        t = np.frombuffer(raw, dtype=np.uint64, count=n * 16, offset=pos + 40).reshape(n, 16)
+        pos += 40 + n * 128
+        report(name, t)
 
 
 main()
