@@ -43,6 +43,11 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   __shared__ uint8_t s_kind[SAFE ? BMAX * T : 1];
   constexpr int N = F::N;
   const uint32_t block_base = blockIdx.x * (uint32_t)(T * B);
+#ifdef MSMZ_TRACE
+  uint64_t* trace = reinterpret_cast<uint64_t*>(meta + 1);   // (the trace build allocates the stamps behind the meta block)
+#endif
+  MSMZ_STAMP(trace, 0);
+  MSMZ_STAMP_HW(trace);
 
   Fe<F> prefix;
   fe_set_const<F>(prefix, F::ONE);
@@ -143,6 +148,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     if (SAFE) s_kind[i * T + threadIdx.x] = (uint8_t)kind;
   }
 
+  MSMZ_STAMP(trace, 1);
   // ---------------------------------------------------------------- workgroup-wide inversion of the T products
   Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
   {
@@ -174,6 +180,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     }
     __syncthreads();
   }
+  MSMZ_STAMP(trace, 2);
   if (threadIdx.x < 64) {
     Fe<F> root, inv;
 #pragma unroll
@@ -191,6 +198,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     }
   }
   __syncthreads();
+  MSMZ_STAMP(trace, 3);
   // down-sweep: one thread per CHILD (inverse of a child = inverse of the parent times the sibling), so a level is one
   // field product deep, not two (the sweep is on the critical path of every batch: ~1.8 us per product when the
   // workgroup's other waves wait at the barrier)
@@ -226,6 +234,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
     fe_mul(run, ninv, partner);
   }
 
+  MSMZ_STAMP(trace, 4);
   // ---------------------------------------------------------------- backward pass
   {
     const uint32_t tl = block_base + (uint32_t)(B - 1) * T + threadIdx.x;
@@ -299,6 +308,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
       slot_store_point<F>(out, dummy, true);
     }
   }
+  MSMZ_STAMP(trace, 5);
 }
 
 }  // namespace msmz

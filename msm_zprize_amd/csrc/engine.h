@@ -167,7 +167,7 @@ class Engine : public IEngine {
     if constexpr (Fr::HAS_GLV) {
       if ((st = raise_sort_limits<true, 0>()) || (st = raise_sort_limits<true, 16>())) return st;
     }
-    return meta_.ensure(sizeof(MsmMeta));
+    return meta_.ensure(sizeof(MsmMeta) + kTraceBytes * 65536);
   }
   template <bool GLV, int C>
   int raise_sort_limits() {
@@ -1248,6 +1248,16 @@ class Engine : public IEngine {
       if (pairs == 0) continue;
       launch_batch_add(pairs, opt.safe != 0, d_points, desc_.as<uint2>() + h_meta_->round_base[r], h_meta_->round_base[r],
                        d_meta);
+#ifdef MSMZ_TRACE
+      {
+        char nm[32];
+        snprintf(nm, sizeof nm, "k_batch_add round %d", r);
+        int B = 1;
+        while (B < 16 && (uint64_t)pairs >= (uint64_t)MSMZ_BATCH_T * (B * 2) * batch_min_wgs_) B *= 2;
+        const uint32_t wgs = (pairs + MSMZ_BATCH_T * B - 1) / (MSMZ_BATCH_T * B);
+        if ((st = trace_dump(nm, d_meta + 1, wgs < 65536 ? wgs : 65536, false))) return st;
+      }
+#endif
       mark(pl);
     }
     const int ev_acc_end = pl.ei;

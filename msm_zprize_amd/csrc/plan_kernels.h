@@ -31,7 +31,7 @@ constexpr int PLAN_RL = 6;                        // rounds whose per-bucket pai
 constexpr int PLAN_TILE = 4096;                   // pairs whose owner buckets are expanded into LDS at a time
 // (LDS: 6 x 4.1 KB of prefixes + 4.1 KB of offsets + 8 KB of owners = 37 KB: FOUR workgroups per CU, so that the 1024
 // chunks of a 2^20-point MSM are resident together; at 53 KB three were, and the fourth quarter ran as a second pass:
-// 95 us instead of ~50, profiles/r03_sort_wg_timeline.txt)
+// 95 us instead of ~50, profiles/r03_wg_timelines.txt)
 constexpr uint32_t LOC_ORIG = 0x40000000u;        // location word: bit 30 = original point (bit 31 = negate), else slot record
 constexpr uint32_t LOC_NONE = 0xffffffffu;
 

@@ -14,6 +14,8 @@ LABELS = {
     "k_plan_emit": {1: "bucket offsets", 2: "chunk totals", 3: "per-round scans", 4: "round 0", 5: "round 1", 6: "round 2",
                     7: "round 3", 8: "round 4", 9: "round 5", 10: "later rounds + bucket records"},
 }
+for _r in range(12):
+    LABELS[f"k_batch_add round {_r}"] = {1: "forward pass", 2: "product tree up", 3: "inversion", 4: "down-sweep", 5: "backward pass"}
 
 
 def report(name, t):
