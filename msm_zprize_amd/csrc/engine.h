@@ -1213,7 +1213,18 @@ class Engine : public IEngine {
     // still spreads over ~4 workgroups per CU
     uint32_t chunk = PLAN_CHUNK;
     while (chunk > 64 && (nb + chunk - 1) / chunk < 1024) chunk >>= 1;
-    const uint32_t n_chunks = (nb + chunk - 1) / chunk;
+    // the top window's bucket sets in half-size chunks when they are denser than the others (plan_kernels.h PlanChunks)
+    PlanChunks pc;
+    pc.chunk = chunk;
+    pc.nb_main = nb;
+    pc.chunk_top = chunk;
+    if (!no_plan_top_ && pl.K > 1 && pl.fold_shift == 0 && chunk >= 128 &&
+        (uint64_t)pl.L * 10 > ((uint64_t)pl.top_range << pl.spread) * 13) {
+      pc.nb_main = (uint32_t)(pl.K - 1) * pl.L;
+      pc.chunk_top = chunk / 2;
+    }
+    pc.n_main = (pc.nb_main + chunk - 1) / chunk;
+    const uint32_t n_chunks = pc.n_main + (nb - pc.nb_main + pc.chunk_top - 1) / pc.chunk_top;
     // chunk totals per round, then the per-workgroup scratch of the rounds beyond PLAN_RL
     const size_t pair_words = (size_t)n_chunks * (PLAN_RMAX - PLAN_RL) * PLAN_T;
     if ((st = rscan_.ensure(((size_t)PLAN_RMAX * n_chunks + pair_words) * 4 + kTraceBytes * n_chunks))) return st;
@@ -1224,10 +1235,10 @@ class Engine : public IEngine {
     const bool r2d = !f2 && reduce2d_ && pl.L >= 2;
     const int tail_skip = f2 ? 0 : (r2d ? tail_skip_2d_ : tail_skip_);
     hipLaunchKernelGGL(k_plan_count, dim3(n_chunks), dim3(PLAN_T), 0, stream_, rscan_.as<uint32_t>(), off_.as<uint32_t>(),
-                       nb, n_chunks, d_meta, tail_skip, chunk);
+                       nb, n_chunks, d_meta, tail_skip, pc);
     hipLaunchKernelGGL(k_plan_emit, dim3(n_chunks), dim3(PLAN_T), 0, stream_, desc_.as<uint2>(), bfin_.as<uint4>(),
                        d_meta, rscan_.as<uint32_t>(), off_.as<uint32_t>(), refs_.as<uint32_t>(), nb, n_chunks,
-                       tail_skip, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks, chunk);
+                       tail_skip, rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks, pc);
     MSMZ_HIP(hipGetLastError());
 #ifdef MSMZ_TRACE
     if ((st = trace_dump("k_plan_emit", rscan_.as<uint32_t>() + (size_t)PLAN_RMAX * n_chunks + pair_words, n_chunks, false))) return st;
@@ -1644,6 +1655,7 @@ class Engine : public IEngine {
   bool no_bucket_sums_ = env_int("MSMZ_NO_BUCKET_SUMS", 0) != 0;
   bool no_window_model_ = env_int("MSMZ_NO_WINDOW_MODEL", 0) != 0;
   bool force_atomic_sort_ = env_int("MSMZ_ATOMIC_SORT", 0) != 0;
+  bool no_plan_top_ = env_int("MSMZ_NO_PLAN_TOP", 0) != 0;            // top-window bucket sets in full-size plan chunks
   bool no_fbt_ = env_int("MSMZ_NO_FBT", 0) != 0;                     // top window's bins as wide as the others
   bool no_sort_special_ = env_int("MSMZ_NO_SORT_SPECIAL", 0) != 0;   // generic sort kernels for every window size
   bool reduce2d_ = env_int("MSMZ_REDUCE2D", 1) != 0;          // two-dimensional bucket reduction (reduce2d_kernels.h); 0 = the grouped running sums

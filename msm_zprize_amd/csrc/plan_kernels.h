@@ -50,18 +50,35 @@ __device__ __forceinline__ uint32_t pairs_in_round(uint32_t size, int r) {   // 
 // chunk_pairs[r * n_chunks + chunk] = pairs of round r in the chunk's buckets, r < PLAN_RMAX
 // `chunk` <= PLAN_CHUNK buckets per workgroup (the host picks it so that there are enough workgroups for the GPU even
 // when a window has few, long buckets).
+// The buckets from `nb_main` on (the top window's bucket sets, up to 2x denser than the others) are cut into chunks of
+// `chunk_top` <= chunk buckets, so that their workgroups do not outlast the rest (a launch ends with its slowest one).
+struct PlanChunks {
+  uint32_t chunk, nb_main, n_main, chunk_top;
+};
+__device__ __forceinline__ void plan_chunk_range(const PlanChunks& pc, uint32_t nb, uint32_t& g0, uint32_t& nbk) {
+  if (blockIdx.x < pc.n_main) {
+    g0 = blockIdx.x * pc.chunk;
+    nbk = pc.nb_main - g0 < pc.chunk ? pc.nb_main - g0 : pc.chunk;
+  } else {
+    g0 = pc.nb_main + (blockIdx.x - pc.n_main) * pc.chunk_top;
+    nbk = nb - g0 < pc.chunk_top ? nb - g0 : pc.chunk_top;
+  }
+}
+
 static __global__ void __launch_bounds__(PLAN_T) k_plan_count(uint32_t* chunk_pairs, const uint32_t* off, uint32_t nb,
                                                               uint32_t n_chunks, const MsmMeta* meta, int tail_skip,
-                                                              uint32_t chunk) {
+                                                              PlanChunks pc) {
   __shared__ uint32_t s_tot[PLAN_RMAX];
   const int R = plan_rounds(meta->max_bucket, tail_skip);
   if (threadIdx.x < PLAN_RMAX) s_tot[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t g0 = blockIdx.x * chunk + threadIdx.x * PLAN_PER;
+  uint32_t c0, nbk;
+  plan_chunk_range(pc, nb, c0, nbk);
+  const uint32_t g0 = c0 + threadIdx.x * PLAN_PER;
   uint32_t size[PLAN_PER];
 #pragma unroll
   for (int q = 0; q < PLAN_PER; q++)
-    size[q] = (threadIdx.x * PLAN_PER + q < chunk && g0 + q < nb) ? off[g0 + q + 1] - off[g0 + q] : 0u;
+    size[q] = threadIdx.x * PLAN_PER + q < nbk ? off[g0 + q + 1] - off[g0 + q] : 0u;
   for (int r = 0; r < R; r++) {
     uint32_t s = 0;
 #pragma unroll
@@ -77,7 +94,7 @@ static __global__ void __launch_bounds__(PLAN_T) k_plan_count(uint32_t* chunk_pa
 static __global__ void __launch_bounds__(PLAN_T, 8) k_plan_emit(uint2* desc, uint4* bfin, MsmMeta* meta,
                                                              const uint32_t* chunk_pairs, const uint32_t* off,
                                                              const uint32_t* refs, uint32_t nb, uint32_t n_chunks,
-                                                             int tail_skip, uint32_t* pair_scratch, uint32_t chunk) {
+                                                             int tail_skip, uint32_t* pair_scratch, PlanChunks pc) {
   __shared__ uint32_t s_before[PLAN_RMAX];              // pairs of round r in the chunks before this one
   __shared__ uint32_t s_total[PLAN_RMAX];               // pairs of round r
   __shared__ uint32_t s_rbase[PLAN_RMAX + 1];           // first record of round r's result array
@@ -99,11 +116,17 @@ static __global__ void __launch_bounds__(PLAN_T, 8) k_plan_emit(uint2* desc, uin
     s_before[threadIdx.x] = 0;
     s_total[threadIdx.x] = 0;
   }
-  const uint32_t g0 = blockIdx.x * chunk;
-  const uint32_t nbk = nb - g0 < chunk ? nb - g0 : chunk;   // buckets of this chunk
+  uint32_t g0, nbk;   // first bucket and number of buckets of this chunk
+  plan_chunk_range(pc, nb, g0, nbk);
   for (uint32_t b = threadIdx.x; b <= nbk; b += PLAN_T) s_start[b] = off[g0 + b];
   __syncthreads();
   MSMZ_STAMP(trace, 1);
+  if (blockIdx.x != 0 && s_start[nbk] == s_start[0]) {
+    // a chunk of empty buckets (the top window's sets beyond its digit range): nothing to schedule, nothing left over;
+    // leaves at once so that a waiting workgroup gets the slot (block 0 stays: it publishes the round totals)
+    for (uint32_t b = threadIdx.x; b < nbk; b += PLAN_T) bfin[g0 + b] = make_uint4(LOC_NONE, LOC_NONE, LOC_NONE, LOC_NONE);
+    return;
+  }
   for (int r = 0; r < R; r++) {
     uint32_t tot = 0, pre = 0;
     for (uint32_t b = threadIdx.x; b < n_chunks; b += PLAN_T) {

@@ -6,9 +6,11 @@
 // are never written to memory: every pass that needs them recomputes them from the 32-byte scalar.
 //
 //   digit l in [1, L] of window k  ->  bucket index l - 1 = (coarse << FB) | fine,  FB <= FINE_MAX_BITS fine bits
-//   coarse bin id = kw * NCB + coarse     (kw = bucket set: window k, or one of the top window's sub-windows)
+//   coarse bin id = kw * NCB + coarse     (kw = bucket set: window k, or one of the top window's sub-windows, whose bins
+//                                          may hold fewer buckets: SortGeom::fbt)
 //
-//   k_hist        reads scalars, counts entries per coarse bin (LDS histogram, one global atomic per bin per WG)
+//   k_hist        reads scalars, counts entries per coarse bin (LDS histogram); one RETURNING global atomic per bin and
+//                 workgroup adds the tile's count to the bin's and tells the tile where its run starts inside the bin
 //   k_bin_scan    exclusive scan of the <= 8192 bin counts (one workgroup)
 //   k_coarse      THE bucket scatter: reads scalars again (32 B each), slices all K windows, ranks a tile's entries
 //                 per bin in LDS and writes (fine | negate | index) words in contiguous runs: 32 B in + 4 K B out per
@@ -26,7 +28,7 @@ constexpr int COARSE_T = 1024;
 constexpr int COARSE_ITEMS = 2;                        // half-scalars (= entries per window) per thread
 constexpr int COARSE_TILE = COARSE_T * COARSE_ITEMS;   // entries per window staged by one workgroup
 constexpr int COARSE_MAX_BINS = 512;                   // bins per window (top window: incl. its sub-windows) the staging supports
-constexpr int SORT_MAX_BINS = 8192;                    // all windows: k_coarse keeps 3 words per bin in LDS (96 KB)
+constexpr int SORT_MAX_BINS = 8192;                    // all windows: k_coarse keeps 2 words per bin in LDS (64 KB)
 constexpr int kMaxWindowsSort = 128;                   // windows a scalar can have (c >= 2)
 constexpr int FINE_MAX_BITS = 11;
 constexpr int FINE_T = 1024;
