@@ -363,20 +363,53 @@ __global__ void __launch_bounds__(COARSE_T, 8) k_coarse(uint32_t* packed_out, co
     const uint32_t per = (nbins + COARSE_T - 1) / COARSE_T;   // consecutive bins per thread
     const uint32_t b0 = threadIdx.x * per;
     const int lncb = g.c - 1 - g.fb;
-    uint32_t sum = 0;
-    for (uint32_t q = 0; q < per; q++) {
-      const uint32_t b = b0 + q;
-      if (b < nbins) sum += row[b];
-    }
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan<COARSE_T>(sum, &total, s_wave);
-    for (uint32_t q = 0; q < per; q++) {
-      const uint32_t b = b0 + q;
-      if (b < nbins) {
-        s_cur[b] = ex;
-        s_delta[b] = bin_base[b] + roff[b] - ex;
-        if ((b & (g.ncb - 1u)) == 0 && (b >> lncb) < (uint32_t)g.K) s_wstart[b >> lncb] = ex;   // ncb is a power of two
-        ex += row[b];
+    uint32_t sum = 0, ex, total;
+    if (per == 1) {
+      // (<= 1024 bins: one bin per thread, three independent loads)
+      const uint32_t cnt = b0 < nbins ? row[b0] : 0u;
+      const uint32_t gb = b0 < nbins ? bin_base[b0] + roff[b0] : 0u;
+      ex = block_exclusive_scan<COARSE_T>(cnt, &total, s_wave);
+      if (b0 < nbins) {
+        s_cur[b0] = ex;
+        s_delta[b0] = gb - ex;
+        if ((b0 & (g.ncb - 1u)) == 0 && (b0 >> lncb) < (uint32_t)g.K) s_wstart[b0 >> lncb] = ex;   // ncb is a power of two
+      }
+    } else {
+      // more bins than threads (>= 2^21 entries per window): the three rows are read COALESCED with every load of a
+      // thread in flight (bin = q * 1024 + thread), parked in LDS, and only then walked in the scan's order (consecutive
+      // bins per thread) -- a thread reading its 4-8 consecutive bins straight from memory paid their latency in turn
+      // (14.7 us of a 43 us workgroup life at 2^23)
+      constexpr int PB = SORT_MAX_BINS / COARSE_T;
+      uint32_t cnt[PB], gb[PB];
+#pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t b = (uint32_t)q * COARSE_T + threadIdx.x;
+        cnt[q] = b < nbins ? row[b] : 0u;
+        gb[q] = b < nbins ? bin_base[b] + roff[b] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < PB; q++) {
+        const uint32_t b = (uint32_t)q * COARSE_T + threadIdx.x;
+        if (b < nbins) {
+          s_cur[b] = cnt[q];
+          s_delta[b] = gb[q];
+        }
+      }
+      __syncthreads();
+      for (uint32_t q = 0; q < per; q++) {
+        const uint32_t b = b0 + q;
+        if (b < nbins) sum += s_cur[b];
+      }
+      ex = block_exclusive_scan<COARSE_T>(sum, &total, s_wave);
+      for (uint32_t q = 0; q < per; q++) {
+        const uint32_t b = b0 + q;
+        if (b < nbins) {
+          const uint32_t c = s_cur[b];
+          s_cur[b] = ex;
+          s_delta[b] -= ex;
+          if ((b & (g.ncb - 1u)) == 0 && (b >> lncb) < (uint32_t)g.K) s_wstart[b >> lncb] = ex;
+          ex += c;
+        }
       }
     }
     if (threadIdx.x == 0) s_wstart[g.K] = total;
