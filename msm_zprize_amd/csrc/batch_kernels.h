@@ -149,6 +149,9 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   }
 
   MSMZ_STAMP(trace, 1);
+  // product tree, inversion and down-sweep are few instructions on the critical path of the batch: at raised wave
+  // priority they are not held up by the other workgroups' passes (accumulate 2.43 -> 2.35 ms at 2^20, 18.4 -> 18.1 at 2^23)
+  __builtin_amdgcn_s_setprio(3);
   // ---------------------------------------------------------------- workgroup-wide inversion of the T products
   Fe<F> run;   // inverse of the product of this thread's denominators = inv(level-1 node) * partner's product
   {
@@ -235,6 +238,7 @@ __global__ void __launch_bounds__(T, OCC) k_batch_add(uint32_t* slots, const uin
   }
 
   MSMZ_STAMP(trace, 4);
+  __builtin_amdgcn_s_setprio(0);   // (the backward pass at priority 1 instead: no difference)
   // ---------------------------------------------------------------- backward pass
   {
     const uint32_t tl = block_base + (uint32_t)(B - 1) * T + threadIdx.x;
