@@ -34,7 +34,6 @@ template <class F>
 __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce2d_partial(uint32_t* part, const uint32_t* slots,
                                                                            const uint32_t* points, const uint4* bfin,
                                                                            R2Geom g, uint32_t total) {
-  constexpr int RW = 2 * F::NW;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const uint32_t per_prob = g.H * g.NC;
@@ -64,59 +63,15 @@ __global__ void __launch_bounds__(128, MSMZ_REDUCE_OCC) k_reduce2d_partial(uint3
     line = g.D + v / g.NC;
     chunk = v - (v / g.NC) * g.NC;
   }
-  Xyzz<F> acc, tmp;
+  Xyzz<F> acc;
   xyzz_set_inf(acc);
-  const uint4 none = make_uint4(LOC_NONE, LOC_NONE, LOC_NONE, LOC_NONE);
-  const uint4* fin_k = bfin + (size_t)kw * g.L;
-  // software pipeline: the final-location word is requested two buckets ahead and the first record one bucket ahead of
-  // the mixed addition that consumes them (the kernel runs at 2 waves per SIMD: nothing else hides the two dependent
-  // memory latencies of a bucket)
-  auto fetch_fin = [&](uint32_t i) -> uint4 {
-    const uint32_t j = j0 + i * step;
-    return (i < count && j >= 1) ? fin_k[j - 1] : none;
-  };
-  auto fetch_rec = [&](uint32_t* w, uint32_t loc, uint32_t& neg) {
-    neg = 0;
-    if (loc == LOC_NONE) return;
-    int cs;
-    const uint32_t* rec = operand_address<F>(loc, slots, points, cs, neg);
-    load_words<F>(w, rec, cs);
-  };
-  uint4 f0 = fetch_fin(0), f1 = fetch_fin(1);
-  uint32_t r0[RW], r1[RW], n0, n1 = 0;
-#pragma unroll
-  for (int q = 0; q < RW; q++) r0[q] = r1[q] = 0;
-  fetch_rec(r0, f0.x, n0);
+  // (A software pipeline -- final-location word two buckets ahead, record one bucket ahead -- measured no faster than
+  // this plain loop once the chunks were interleaved: the kernel is bound by the multiplier at 2 waves per SIMD, and the
+  // other wave covers the two dependent loads of a bucket.)
 #pragma unroll 1
   for (uint32_t i = 0; i < count; i++) {
-    const uint4 f2 = fetch_fin(i + 2);
-    fetch_rec(r1, f1.x, n1);
-    if (f0.x != LOC_NONE) {
-      uint32_t o = 0;
-#pragma unroll
-      for (int q = 0; q < RW; q++) o |= r0[q];
-      Affine<F> p;
-      Fe<F> y;
-      fe_unpack<F>(p.x, r0);
-      fe_unpack<F>(y, r0 + F::NW);
-      fe_cneg(p.y, y, n0);
-      xyzz_madd(tmp, acc, p, o == 0);
-      acc = tmp;
-      // further partial sums of a long bucket (rare: the tree rounds stop one short of the longest bucket)
-      const uint32_t more[3] = {f0.y, f0.z, f0.w};
-#pragma unroll 1
-      for (int m = 0; m < 3; m++) {
-        if (more[m] == LOC_NONE) break;
-        const bool inf = load_operand<F, true>(p, more[m], slots, points);
-        xyzz_madd(tmp, acc, p, inf);
-        acc = tmp;
-      }
-    }
-    f0 = f1;
-    f1 = f2;
-    n0 = n1;
-#pragma unroll
-    for (int q = 0; q < RW; q++) r0[q] = r1[q];
+    const uint32_t j = j0 + i * step;
+    if (j >= 1) add_bucket<F>(acc, kw * g.L + (j - 1), slots, points, bfin);
   }
   if (!col && line == g.H / 2 && chunk == 0) {
     // the single bucket of weight L = H D is folded in as 2 * (H/2) * D
