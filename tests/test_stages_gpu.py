@@ -187,7 +187,7 @@ def test_bucket_sort_membership(ctxs, label, glv, fallback):
     n = 3000
     scalars = [rng.randrange(q) for _ in range(n - 300)] + [rng.choice([5, q - 5, 1 << 77]) for _ in range(300)]
     lam = cv.get("endomorphism", {}).get("lambda_")
-    for c in (5, 11):
+    for c in (5, 11, 16, 17):   # 16 / 17: the sort kernels specialized for the default window sizes (unrolled window loop)
         g, off, refs = _sort(curve, scalars, c, glv, fallback)
         K, L, Keff = g["K"], g["L"], g["Keff"]
         assert g["c"] == c and L == 1 << (c - 1) and g["nb"] == Keff * L and off[0] == 0 and off[-1] == g["E"]
