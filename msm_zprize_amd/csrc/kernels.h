@@ -952,6 +952,7 @@ struct WeierPolicy {
   using Acc = Xyzz<F>;
   static constexpr int IN_WORDS = PointFmt<F>::STRIDE;   // words between the records of a resident point set
   static constexpr int ACC_WORDS = 4 * F::NW;
+  static constexpr int ACC_OCC = 1;   // k_bucket_accumulate: no register cap (the XYZZ mixed addition spills below ~120)
   static __device__ __forceinline__ void zero(Acc& a) { xyzz_set_inf(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { xyzz_add(r, a, b); }
   static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { xyzz_dbl(r, a); }
@@ -982,6 +983,12 @@ struct TePolicy {
   using Acc = TeExt<F>;
   static constexpr int IN_WORDS = 4 * F::NW;   // Niels record padded to 4 field elements (16-byte aligned loads)
   static constexpr int ACC_WORDS = 4 * F::NW;
+#ifndef MSMZ_TE_ACC_OCC
+#define MSMZ_TE_ACC_OCC 5
+#endif
+  // waves per SIMD k_bucket_accumulate's registers are capped for: the 7-product mixed addition fits 91 registers without
+  // spills, one more wave per SIMD behind the random 128-byte gathers (ed-on-bls12-377 2^24: 16.4 -> 16.0 ms)
+  static constexpr int ACC_OCC = MSMZ_TE_ACC_OCC;
   static __device__ __forceinline__ void zero(Acc& a) { te_set_zero(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { te_add(r, a, b); }
   static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { te_add(r, a, a); }
@@ -1016,7 +1023,7 @@ struct TePolicy {
 constexpr int ACC_CHUNK_SHIFT = 5;   // normal chunk = 32 entries (64 measured 4 % slower on Pallas 2^22); the host raises it to ~sqrt(longest bucket)
 
 template <class P>
-__global__ void __launch_bounds__(128) k_bucket_accumulate(uint32_t* partial, const uint32_t* points,
+__global__ void __launch_bounds__(128, P::ACC_OCC) k_bucket_accumulate(uint32_t* partial, const uint32_t* points,
                                                            const uint32_t* refs, const uint32_t* off,
                                                            const uint32_t* cscan, uint32_t nb, uint32_t n_chunks,
                                                            int chunk_shift) {
