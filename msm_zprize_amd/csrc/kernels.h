@@ -983,12 +983,9 @@ struct TePolicy {
   using Acc = TeExt<F>;
   static constexpr int IN_WORDS = 4 * F::NW;   // Niels record padded to 4 field elements (16-byte aligned loads)
   static constexpr int ACC_WORDS = 4 * F::NW;
-#ifndef MSMZ_TE_ACC_OCC
-#define MSMZ_TE_ACC_OCC 5
-#endif
-  // waves per SIMD k_bucket_accumulate's registers are capped for: the 7-product mixed addition fits 91 registers without
-  // spills, one more wave per SIMD behind the random 128-byte gathers (ed-on-bls12-377 2^24: 16.4 -> 16.0 ms)
-  static constexpr int ACC_OCC = MSMZ_TE_ACC_OCC;
+  // k_bucket_accumulate: no register cap (a cap for 5 waves per SIMD -- 91 registers, no spills -- measured 1 % slower
+  // in a same-box A/B at 2^24, 6 waves spill)
+  static constexpr int ACC_OCC = 1;
   static __device__ __forceinline__ void zero(Acc& a) { te_set_zero(a); }
   static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { te_add(r, a, b); }
   static __device__ __forceinline__ void dbl(Acc& r, const Acc& a) { te_add(r, a, a); }
