@@ -450,3 +450,28 @@ def test_thin_top_window_is_folded(curves, label, glv, c):
             # unfolded, the top window's <= 4 digit values x <= 8 sub-windows would hold >= n / 32 entries per bucket
             assert out["stats"].max_bucket < n // 32, out["stats"].max_bucket
         pts.free(); sc.free()
+
+
+@pytest.mark.parametrize("label,c", [("bls12-377", 17), ("bls12-377", 16), ("pallas", 16), ("bls12-381", 0)])
+def test_tile_boundaries_and_extreme_scalars(curves, label, c):
+    """Sizes around the bucket sort's tile of 2048 scalars (one scalar short of a tile, a full tile, one scalar into the
+    next, two tiles and one) at the window sizes whose sort kernels are specialized (16 / 17), with scalars that sit at
+    the edges of the digit range: 0, 1, q - 1 (largest top-window digit), 2^k - 1 (all-ones windows: every digit carries),
+    2^k (one non-zero window) -- among random ones.  msmUnsafe with GLV on / off and msm (safe) against the oracle."""
+    curve = curves(label)
+    q = P.CURVES[label]["order"]
+    rng = random.Random(77)
+    for n in (2047, 2048, 2049, 4097):
+        pts = curve.Parallel.randomPointsFast(n, 500 + n)
+        points = curve.Affine.toBigints(pts)
+        edge = [0, 1, q - 1, q - 2, (1 << 200) - 1, 1 << 200, (1 << 17) - 1, 1 << 17, (1 << 16), (1 << 252) % q]
+        scalars = [rng.randrange(q) for _ in range(n)]
+        for i, e in enumerate(edge):
+            scalars[(i * 211) % n] = e
+            scalars[n - 1 - i] = e
+        sc = curve.Parallel.scalarsFromBigints(scalars)
+        want = _oracle(label, scalars, points)
+        for glv in (0, 1):
+            assert curve.Parallel.msmUnsafe(sc, pts, n, True, {"glv": glv, "c": c})["result"] == want, (n, glv)
+        assert curve.Parallel.msm(sc, pts, n, False, {"glv": 0, "c": c})["result"] == want, (n, "safe")
+        pts.free(); sc.free()
